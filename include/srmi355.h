@@ -1,0 +1,253 @@
+/*
+ * srmi355 — C ABI of the MI355X (gfx950) super-resolution inference library.
+ *
+ * Plain C: pointers, sizes and PODs only.  Every function returns 0 on success and -1 on
+ * failure (the convention of the reference runners, edsr/mtk/cpp/jni/src/edsr.cpp:216-219);
+ * srmi_last_error() returns the message of the calling thread's last failure.
+ *
+ * Three layers are exported:
+ *   1. operator level  (srmi_conv3x3, srmi_conv_first, srmi_ca_*, srmi_pixel_shuffle, ...):
+ *      one HIP kernel launch each, device pointers in / out.  These replace the torch ops the
+ *      reference modules call (nn.Conv2d + activation + residual, nn.PixelShuffle,
+ *      F.interpolate(nearest), CALayer) — see the citation on each declaration.
+ *   2. model level (srmi_model_*): a whole-network executor for EDSR / RCAN / RRDBNet that takes
+ *      the reference's state_dict tensors by name and runs forward(img) on a HIP stream.
+ *   3. runner level (include/edsr.h, rcan.h, realesrgan.h): the reference's own extern "C"
+ *      runner API (<m>_init / <m>_inference / <m>_inference_ex / <m>_release) on host buffers.
+ *
+ * Device tensor layout ("planes"): an activation tensor of C channels is stored as
+ * [N][C/CPB][H][W][CPB] with CPB = 64 bytes / sizeof(element): 32 channels per plane for
+ * f16/bf16, 16 for f32.  A pixel of one plane is therefore always 64 bytes.
+ * Strides in this header are in ELEMENTS of the tensor's own dtype.
+ */
+#ifndef SRMI355_H_
+#define SRMI355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types */
+#define SRMI_F32 0
+#define SRMI_F16 1
+#define SRMI_BF16 2
+
+/* activations fused into the conv epilogue */
+#define SRMI_ACT_NONE 0
+#define SRMI_ACT_RELU 1   /* nn.ReLU            (edsr_model.py:87, rcan_model.py:128) */
+#define SRMI_ACT_LRELU 2  /* nn.LeakyReLU(0.2)  (realesrgan_model.py:23,94) */
+
+/* float -> u8 rounding of the different reference runners */
+#define SRMI_ROUND_HALF_EVEN 0 /* torch .round()      (realesrgan/mtk/python/test/test_pytorch.py:73-76) */
+#define SRMI_ROUND_HALF_UP 1   /* (uint8)(v + 0.5f)   (realesrgan.cpp:124-126, edsr.cpp:116-118) */
+#define SRMI_ROUND_TRUNC 2     /* astype(uint8)       (edsr/mtk/python/test/test_pytorch.py:60-61) */
+
+/* network-input encodings accepted by srmi_conv_first / srmi_model_forward */
+#define SRMI_IN_F32_NCHW 0
+#define SRMI_IN_U8_NHWC 1
+
+/* RGB tail encodings produced by the last conv */
+#define SRMI_TAIL_NONE 0
+#define SRMI_TAIL_F32_NCHW 1
+#define SRMI_TAIL_U8_NHWC 2
+
+const char* srmi_last_error(void);
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int srmi_device_count(void);
+/* Library build info string (arch, version). */
+const char* srmi_version(void);
+
+/* ------------------------------------------------------------------------------------------ *
+ * 1. Operator level
+ * ------------------------------------------------------------------------------------------ */
+
+/* A view of a plane-layout device tensor. */
+typedef struct {
+    void* ptr;            /* device pointer to plane 0 of image 0 (NULL = absent) */
+    int64_t img_stride;   /* elements between images */
+    int64_t plane_stride; /* elements between planes */
+    int32_t dtype;        /* SRMI_F32 / SRMI_F16 / SRMI_BF16 */
+    int32_t reserved;
+} srmi_tensor_t;
+
+/*
+ * 3x3, stride 1, zero-padding 1 convolution with fused epilogue; replaces
+ * nn.Conv2d(cin, cout, 3, padding=1) (edsr_model.py:11-15, rcan_model.py:17-18,
+ * realesrgan_model.py:18-22,73-92) plus the elementwise ops that follow it in the reference
+ * forward passes:
+ *
+ *   v   = act(conv(in) + bias)
+ *   v   = v * alpha + res1          (if res1.ptr)   ResBlock / RDB / RCAB-group residuals
+ *   v   = v * beta  + res2          (if res2.ptr)   RRDB outer residual (realesrgan_model.py:49)
+ *   out[.., out_c0 ..]   = v        (if out.ptr; cast to out.dtype; PixelShuffle(ps_r) store)
+ *   out2                 = v        (if out2.ptr; second copy, usually the f32 trunk)
+ *   chansum[n][tile][c]  = sum over the tile's pixels of v   (if chansum; CALayer pooling)
+ *   tail: rgb = tail_mat * v[0:3] + tail_bias -> f32 NCHW, or clamp/scale/round -> u8 NHWC
+ *
+ * `h`,`w` are the conv's spatial size.  With in_up2 the input tensor is (h/2, w/2) and is read
+ * through F.interpolate(scale_factor=2, mode='nearest') (realesrgan_model.py:110,113).
+ * With ps_r > 1 the `cout` output channels are stored as nn.PixelShuffle(ps_r) would
+ * (edsr_model.py:57,67): out is (h*ps_r, w*ps_r) with cout/ps_r^2 channels.
+ * cin must be a multiple of the plane width; cout a multiple of 32, or 3 with a tail.
+ * Weights come from srmi_pack_conv3x3 for the same (dtype, cout_tile, ps_r).
+ */
+typedef struct {
+    int32_t dtype;       /* compute element type: type of `in` and of the packed weights */
+    int32_t n, h, w;
+    int32_t cin, cout;
+    int32_t in_up2;
+    int32_t act;
+    int32_t ps_r;        /* 1 (none), 2 or 3 */
+    int32_t cout_tile;   /* 32 or 64: output channels per workgroup (must match the packing) */
+    int32_t rows_per_wave; /* 0 = library default; 2, 3 or 4 */
+    int32_t tail_mode;   /* SRMI_TAIL_* */
+    srmi_tensor_t in;
+    const void* wpk;     /* packed weights (device) */
+    const float* bias;   /* packed-order bias, float[cout padded to cout_tile] (device) */
+    float alpha, beta;
+    srmi_tensor_t res1, res2;
+    srmi_tensor_t out, out2;
+    float* chansum;      /* float[n][tiles][cout] or NULL */
+    void* tail_out;
+    float tail_mat[9];
+    float tail_bias[3];
+    float tail_lo, tail_hi, tail_scale;
+    int32_t tail_round;
+} srmi_conv_desc_t;
+
+int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream);
+/* Number of spatial tiles per image srmi_conv3x3 uses for (h, w, rows_per_wave): the middle
+ * extent of `chansum`. */
+int srmi_conv3x3_tiles(int h, int w, int rows_per_wave);
+
+/* Bytes of the packed form of an OIHW [cout][cin][3][3] weight; bias_floats receives the padded
+ * bias length. */
+size_t srmi_pack_conv3x3_bytes(int dtype, int cout, int cin, int cout_tile, int* bias_floats);
+/* Host-side repack: OIHW f32 -> the device image the conv kernel stages into LDS.
+ * `bias` may be NULL (zeros). Output buffers are host memory. */
+int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, int ps_r,
+                      const float* w_oihw, const float* bias, void* wpk_out, float* bias_out);
+
+/*
+ * First layer: 3-channel input -> cout channels.  Fuses the network's pre-processing
+ * (MeanShift sub_mean as a general 3x3 matrix + bias, edsr_model.py:18-26,115; or the runners'
+ * u8 -> float conversion, edsr.cpp:21-41, realesrgan.cpp:28-48) into the loader: the affine map
+ * is applied to in-bounds pixels only, so zero padding stays zero in the shifted domain.
+ *   in_kind SRMI_IN_F32_NCHW: float [n][3][h][w];  SRMI_IN_U8_NHWC: uint8 [n][h][w][3].
+ * w_kcio: float [3][3][3][cout] (ky, kx, cin, cout) on the device; bias float[cout].
+ */
+typedef struct {
+    int32_t n, h, w, cout;
+    int32_t in_kind;
+    int32_t reserved;
+    const void* in;
+    float pre_mat[9];
+    float pre_bias[3];
+    const float* w_kcio;
+    const float* bias;
+    srmi_tensor_t out, out2;
+} srmi_conv_first_desc_t;
+
+int srmi_conv_first(const srmi_conv_first_desc_t* d, void* hip_stream);
+
+/*
+ * CALayer (rcan_model.py:61-76), split at its global dependency:
+ *   srmi_ca_scale : mean = sum(chansum over tiles) / (h*w); z = relu(W1 mean + b1);
+ *                   s = sigmoid(W2 z + b2)                      -> scale[n][c]
+ *   srmi_ca_apply : out = x + res_scale * (y * s[c])   (RCAB.forward, rcan_model.py:94-97)
+ * w1: float[cr][c], w2: float[c][cr] (the 1x1 conv weights, device pointers).
+ */
+int srmi_ca_scale(const float* chansum, int n, int tiles, int c, int cr, int hw,
+                  const float* w1, const float* b1, const float* w2, const float* b2,
+                  float* scale, void* hip_stream);
+int srmi_ca_apply(const srmi_tensor_t* y, const srmi_tensor_t* x, const float* scale,
+                  float res_scale, int n, int h, int w, int c,
+                  const srmi_tensor_t* out, const srmi_tensor_t* out2, void* hip_stream);
+
+/* Per-(n, c) sums over H*W of a plane tensor: AdaptiveAvgPool2d(1) numerator
+ * (rcan_model.py:65,74) as a standalone wavefront reduction.  sums: float[n][c]. */
+int srmi_channel_sums(const srmi_tensor_t* x, int n, int h, int w, int c, float* sums,
+                      void* hip_stream);
+
+/* Standalone coalesced permutes on plane tensors (same dtype in and out):
+ * nn.PixelShuffle(r) (edsr_model.py:57,67; rcan_model.py:44,51) and
+ * F.interpolate(scale_factor=2, mode='nearest') (realesrgan_model.py:110,113). */
+int srmi_pixel_shuffle(const srmi_tensor_t* in, const srmi_tensor_t* out, int n, int h, int w,
+                       int c_in, int r, void* hip_stream);
+int srmi_nearest_up2(const srmi_tensor_t* in, const srmi_tensor_t* out, int n, int h, int w,
+                     int c, void* hip_stream);
+
+/* Layout conversion between float NCHW and plane tensors (test / interop helpers). */
+int srmi_nchw_to_planes(const float* in, const srmi_tensor_t* out, int n, int c, int h, int w,
+                        void* hip_stream);
+int srmi_planes_to_nchw(const srmi_tensor_t* in, float* out, int n, int c, int h, int w,
+                        void* hip_stream);
+
+/* Bilinear u8 HWC resize of the runners (edsr.cpp:46-94): top-left aligned, x1/y1 clamped,
+ * (uint8)(val + 0.5f).  Device pointers. */
+int srmi_resize_bilinear_u8(const uint8_t* in, int in_w, int in_h, uint8_t* out, int out_w,
+                            int out_h, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * 2. Model level
+ * ------------------------------------------------------------------------------------------ */
+
+#define SRMI_ARCH_EDSR 1    /* edsr_model.py:80-124 */
+#define SRMI_ARCH_RCAN 2    /* rcan_model.py:119-159 */
+#define SRMI_ARCH_RRDBNET 3 /* realesrgan_model.py:60-123 */
+
+typedef struct {
+    int32_t arch;
+    int32_t dtype;        /* compute dtype SRMI_F32 / SRMI_F16 / SRMI_BF16 */
+    int32_t scale;        /* 2, 3, 4, 8 (RRDBNet: 2 or 4) */
+    int32_t n_feats;      /* EDSR 256, RCAN 64, RRDBNet num_feat 64 */
+    int32_t n_blocks;     /* EDSR n_resblocks, RCAN n_resblocks per group, RRDBNet num_block */
+    int32_t n_groups;     /* RCAN n_resgroups (else 0) */
+    int32_t grow_ch;      /* RRDBNet num_grow_ch (else 0) */
+    int32_t reduction;    /* RCAN reduction (else 0) */
+    float res_scale;      /* EDSR 0.1, RCAN 1.0 */
+    int32_t with_meanshift; /* 1: EDSR / RCAN full model (sub_mean/add_mean from the state_dict);
+                               0: *Core variants (edsr_model.py:146, rcan_model.py:166) */
+    int32_t trunk_f32;    /* half dtypes only: keep the residual trunk in f32 */
+    int32_t device;       /* HIP device ordinal */
+} srmi_model_desc_t;
+
+typedef struct srmi_model srmi_model_t;
+
+int srmi_model_create(const srmi_model_desc_t* desc, srmi_model_t** out);
+void srmi_model_destroy(srmi_model_t* m);
+/* Hand over one state_dict entry (host memory, float32, contiguous, the reference's key names
+ * and shapes, i.e. the module trees of edsr_model.py / rcan_model.py / realesrgan_model.py).  Unknown keys or wrong shapes fail. */
+int srmi_model_set_tensor(srmi_model_t* m, const char* key, const float* data,
+                          const int64_t* shape, int ndim);
+/* Number of state_dict keys the architecture expects, and the i-th key. */
+int srmi_model_num_keys(const srmi_model_t* m);
+const char* srmi_model_key(const srmi_model_t* m, int i);
+/* Pack and upload the weights.  Fails if a key is missing (strict=True semantics). */
+int srmi_model_finalize(srmi_model_t* m);
+
+/* forward(x): f32 NCHW [n][3][h][w] -> f32 NCHW [n][3][h*scale][w*scale], device pointers.
+ * EDSR/RCAN: 0..rgb_range domain including MeanShift; RRDBNet: [0,1], no clamp. */
+int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* out, int n, int h, int w,
+                           void* hip_stream);
+/* Runner path: u8 NHWC in -> u8 NHWC out (device pointers) with the runners' pre/post fused:
+ * RRDBNet p/255 ... clamp(v,0,1)*255 (realesrgan.cpp:28-48,110-130); EDSR/RCAN p - mean*range ...
+ * clamp(v + mean*range, 0, 255) (edsr.cpp:21-41,101-122). */
+int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
+                          int round_mode, void* hip_stream);
+/* Bytes of device workspace currently held by the model (grows with the largest n*h*w seen). */
+size_t srmi_model_workspace_bytes(const srmi_model_t* m);
+/* Images a forward call sweeps through each layer together (default 1: one image per
+ * layer sweep keeps its activations in the 256 MiB Infinity Cache). */
+int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep);
+/* Algorithmic conv FLOPs (2*Cin*Cout*9 per output pixel of every conv) of one forward at
+ * (h, w) input size. */
+double srmi_model_flops(const srmi_model_t* m, int h, int w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRMI355_H_ */

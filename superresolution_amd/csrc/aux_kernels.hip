@@ -1,0 +1,437 @@
+// HBM-bound kernels around the convolutions: the 3-channel first layer with fused
+// pre-processing, channel attention (pooling finish + scale/residual apply), standalone
+// PixelShuffle / nearest-x2 permutes, float-NCHW <-> plane layout conversion and the runners'
+// bilinear u8 resize.  All of them move 8-16 bytes per lane with consecutive lanes on
+// consecutive addresses.
+#include "common.h"
+#include "devutil.h"
+
+namespace srmi {
+
+// ------------------------------------------------------------------------------------------------
+// First layer (cin = 3): one thread = one pixel x 4 output channels.
+// ------------------------------------------------------------------------------------------------
+struct FirstParams {
+    int n, h, w, cout, in_kind;
+    const void* in;
+    float pre_mat[9];
+    float pre_bias[3];
+    const float* wgt;   // [27][cout]
+    const float* bias;  // [cout]
+    TView out, out2;
+};
+
+__device__ __forceinline__ float pre_affine(const float* m, float b, const float (&raw)[3]) {
+#pragma clang fp contract(off)
+    // every product and sum individually rounded, in the order a 1x1 conv / the runners' scalar
+    // code evaluates them
+    return ((m[0] * raw[0] + m[1] * raw[1]) + m[2] * raw[2]) + b;
+}
+
+__global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
+    const int groups = p.cout >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.n * p.h * p.w * groups;
+    if (idx >= total) return;
+    const int cg = (int)(idx % groups);
+    long long pixn = idx / groups;
+    const int x = (int)(pixn % p.w);
+    pixn /= p.w;
+    const int y = (int)(pixn % p.h);
+    const int n = (int)(pixn / p.h);
+    const long long hw = (long long)p.h * p.w;
+
+    f32x4 acc = *(const f32x4*)(p.bias + cg * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            float v[3] = {0.f, 0.f, 0.f};
+            if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
+                float raw[3];
+                if (p.in_kind == SRMI_IN_U8_NHWC) {
+                    const unsigned char* s = (const unsigned char*)p.in + ((long long)n * hw + (long long)yy * p.w + xx) * 3;
+                    raw[0] = (float)s[0]; raw[1] = (float)s[1]; raw[2] = (float)s[2];
+                } else {
+                    const float* s = (const float*)p.in + (long long)n * 3 * hw + (long long)yy * p.w + xx;
+                    raw[0] = s[0]; raw[1] = s[hw]; raw[2] = s[2 * hw];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = pre_affine(p.pre_mat + 3 * c, p.pre_bias[c], raw);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 wv = *(const f32x4*)(p.wgt + (long long)((ky * 3 + kx) * 3 + c) * p.cout + cg * 4);
+                acc += wv * v[c];
+            }
+        }
+    }
+    const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+    const long long pix = (long long)y * p.w + x;
+    if (p.out.ptr) store4(p.out, n, pix, cg * 4, o);
+    if (p.out2.ptr) store4(p.out2, n, pix, cg * 4, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel attention
+// ------------------------------------------------------------------------------------------------
+// One workgroup per image: finish the pooling (fixed summation order -> bitwise reproducible),
+// then the squeeze / excite 1x1 convolutions and the sigmoid.
+__global__ __launch_bounds__(256) void ca_scale_kernel(const float* chansum, int tiles, int c, int cr,
+                                                       float inv_hw, const float* w1, const float* b1,
+                                                       const float* w2, const float* b2, float* scale) {
+    extern __shared__ float sh[];  // [4][c] partials, [c] mean, [cr] z
+    float* part = sh;
+    float* mean = sh + 4 * c;
+    float* z = mean + c;
+    const int n = blockIdx.x;
+    const float* src = chansum + (long long)n * tiles * c;
+    for (int i = threadIdx.x; i < 4 * c; i += 256) {
+        const int ch = i % c, q = i / c;
+        float s = 0.f;
+        for (int t = q; t < tiles; t += 4) s += src[(long long)t * c + ch];
+        part[q * c + ch] = s;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256)
+        mean[ch] = ((part[ch] + part[c + ch]) + (part[2 * c + ch] + part[3 * c + ch])) * inv_hw;
+    __syncthreads();
+    for (int j = threadIdx.x; j < cr; j += 256) {
+        float s = b1[j];
+        for (int ch = 0; ch < c; ++ch) s += w1[j * c + ch] * mean[ch];
+        z[j] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float s = b2[ch];
+        for (int j = 0; j < cr; ++j) s += w2[ch * cr + j] * z[j];
+        scale[(long long)n * c + ch] = 1.f / (1.f + expf(-s));
+    }
+}
+
+// out = x + res_scale * (y * s[c]); one thread = one pixel x 8 channels (two 4-channel groups).
+__global__ __launch_bounds__(256) void ca_apply_kernel(TView y, TView x, const float* scale, float res_scale,
+                                                       int n_img, long long hw, int c, TView out, TView out2) {
+    const int groups = c >> 3;
+    const long long total = (long long)n_img * hw * groups;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int g = (int)(idx % groups);
+        const long long pn = idx / groups;
+        const long long pix = pn % hw;
+        const int n = (int)(pn / hw);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int ch = g * 8 + half * 4;
+            float yv[4], xv[4], o[4];
+            load4(y, n, pix, ch, yv);
+            load4(x, n, pix, ch, xv);
+            const f32x4 s = *(const f32x4*)(scale + (long long)n * c + ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (yv[j] * s[j]) * res_scale + xv[j];
+            if (out.ptr) store4(out, n, pix, ch, o);
+            if (out2.ptr) store4(out2, n, pix, ch, o);
+        }
+    }
+}
+
+// Per-(n, c) sums over all pixels: each workgroup reduces a pixel segment of one 4-channel group
+// slice with wavefront shuffles, then one float atomic per channel per workgroup.
+__global__ __launch_bounds__(256) void channel_sums_kernel(TView x, long long hw, int c, float* sums, int seg) {
+    const int groups = c >> 2;
+    const int n = blockIdx.z;
+    const int gslot = threadIdx.x % 16;              // 16 channel groups in flight per block
+    const int g = blockIdx.y * 16 + gslot;
+    const int prow = threadIdx.x / 16;               // 16 pixel rows per block step
+    const long long p_begin = (long long)blockIdx.x * seg;
+    const long long p_end = p_begin + seg < hw ? p_begin + seg : hw;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < groups) {
+        for (long long pix = p_begin + prow; pix < p_end; pix += 16) {
+            float v[4];
+            load4(x, n, pix, g * 4, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        }
+    }
+    // lanes with equal gslot: xor over bits 4,5 inside the wave, then 4 waves through LDS
+    __shared__ float red[4][16][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc[j] += __shfl_xor(acc[j], 16);
+        acc[j] += __shfl_xor(acc[j], 32);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave][lane][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int gs = threadIdx.x >> 2, j = threadIdx.x & 3;
+        const int gg = blockIdx.y * 16 + gs;
+        if (gg < groups) {
+            const float s = (red[0][gs][j] + red[1][gs][j]) + (red[2][gs][j] + red[3][gs][j]);
+            atomicAdd(sums + (long long)n * c + gg * 4 + j, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Permutes.  One thread = one output pixel x one 16-byte chunk.
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(TView in, TView out, int n_img, int h, int w,
+                                                            int c_out, int r) {
+    constexpr int EPC = 16 / (int)sizeof(E);      // elements per chunk
+    constexpr int CPB = 64 / (int)sizeof(E);
+    const int chunks = c_out / EPC;
+    const int oh = h * r, ow = w * r;
+    const long long total = (long long)n_img * oh * ow * chunks;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int ck = (int)(idx % chunks);
+        long long t = idx / chunks;
+        const int ox = (int)(t % ow); t /= ow;
+        const int oy = (int)(t % oh);
+        const int n = (int)(t / oh);
+        const int y = oy / r, x = ox / r, ij = (oy - y * r) * r + (ox - x * r);
+        const char* ibase = in.ptr + (long long)n * in.img_stride_b + ((long long)y * w + x) * 64;
+        __attribute__((aligned(16))) E v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int ci = (ck * EPC + e) * r * r + ij;
+            v[e] = *(const E*)(ibase + (long long)(ci / CPB) * in.plane_stride_b + (ci % CPB) * sizeof(E));
+        }
+        const int co = ck * EPC;
+        char* o = out.ptr + (long long)n * out.img_stride_b + (long long)(co / CPB) * out.plane_stride_b +
+                  ((long long)oy * ow + ox) * 64 + (co % CPB) * sizeof(E);
+        *(u32x4*)o = *(const u32x4*)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void nearest_up2_kernel(TView in, TView out, int n_img, int h, int w, int planes) {
+    const int oh = 2 * h, ow = 2 * w;
+    const long long total = (long long)n_img * planes * oh * ow * 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int ck = (int)(idx & 3);
+        long long t = idx >> 2;
+        const int ox = (int)(t % ow); t /= ow;
+        const int oy = (int)(t % oh); t /= oh;
+        const int pl = (int)(t % planes);
+        const int n = (int)(t / planes);
+        const char* s = in.ptr + (long long)n * in.img_stride_b + (long long)pl * in.plane_stride_b +
+                        ((long long)(oy >> 1) * w + (ox >> 1)) * 64 + ck * 16;
+        char* d = out.ptr + (long long)n * out.img_stride_b + (long long)pl * out.plane_stride_b +
+                  ((long long)oy * ow + ox) * 64 + ck * 16;
+        *(u32x4*)d = *(const u32x4*)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// float NCHW <-> planes (any plane dtype).  One thread = one pixel x 4 channels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* in, TView out, int n_img, int c, int c_pad,
+                                                             long long hw) {
+    const int groups = c_pad >> 2;
+    const long long total = (long long)n_img * groups * hw;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long pix = idx % hw;
+        long long t = idx / hw;
+        const int g = (int)(t % groups);
+        const int n = (int)(t / groups);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = g * 4 + j;
+            v[j] = ch < c ? in[((long long)n * c + ch) * hw + pix] : 0.f;
+        }
+        store4(out, n, pix, g * 4, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void planes_to_nchw_kernel(TView in, float* out, int n_img, int c, long long hw) {
+    const int groups = (c + 3) >> 2;
+    const long long total = (long long)n_img * groups * hw;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long pix = idx % hw;
+        long long t = idx / hw;
+        const int g = (int)(t % groups);
+        const int n = (int)(t / groups);
+        float v[4];
+        load4(in, n, pix, g * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = g * 4 + j;
+            if (ch < c) out[((long long)n * c + ch) * hw + pix] = v[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear u8 resize of the runners; every float operation individually rounded (no FMA
+// contraction) in the order the scalar host code evaluates them.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(const unsigned char* in, int in_w, int in_h,
+                                                                 unsigned char* out, int out_w, int out_h,
+                                                                 float x_ratio, float y_ratio) {
+#pragma clang fp contract(off)
+    const long long total = (long long)out_w * out_h;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int x = (int)(idx % out_w), y = (int)(idx / out_w);
+        const float px = (float)x * x_ratio, py = (float)y * y_ratio;
+        const int x0 = (int)px, y0 = (int)py;
+        int x1 = x0 + 1, y1 = y0 + 1;
+        if (x1 >= in_w) x1 = in_w - 1;
+        if (y1 >= in_h) y1 = in_h - 1;
+        const float dx = px - (float)x0, dy = py - (float)y0;
+        const float w00 = (1.f - dx) * (1.f - dy);
+        const float w01 = dx * (1.f - dy);
+        const float w10 = (1.f - dx) * dy;
+        const float w11 = dx * dy;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float p00 = in[((long long)y0 * in_w + x0) * 3 + c];
+            const float p01 = in[((long long)y0 * in_w + x1) * 3 + c];
+            const float p10 = in[((long long)y1 * in_w + x0) * 3 + c];
+            const float p11 = in[((long long)y1 * in_w + x1) * 3 + c];
+            const float v = ((w00 * p00 + w01 * p01) + w10 * p10) + w11 * p11;
+            out[idx * 3 + c] = (unsigned char)(v + 0.5f);
+        }
+    }
+}
+
+static inline int grid_for(long long total, int per_block = 256, int cap = 256 * 16) {
+    long long g = (total + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace srmi
+
+using namespace srmi;
+
+extern "C" int srmi_conv_first(const srmi_conv_first_desc_t* d, void* hip_stream) {
+    if (!d) SRMI_FAIL("srmi_conv_first: null descriptor");
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->cout % 32)
+        SRMI_FAIL("srmi_conv_first: bad shape n=%d h=%d w=%d cout=%d", d->n, d->h, d->w, d->cout);
+    if (!d->in || !d->w_kcio || !d->bias || (!d->out.ptr && !d->out2.ptr)) SRMI_FAIL("srmi_conv_first: null pointer");
+    if (d->in_kind != SRMI_IN_F32_NCHW && d->in_kind != SRMI_IN_U8_NHWC) SRMI_FAIL("srmi_conv_first: bad in_kind");
+    FirstParams p;
+    p.n = d->n; p.h = d->h; p.w = d->w; p.cout = d->cout; p.in_kind = d->in_kind;
+    p.in = d->in;
+    for (int i = 0; i < 9; ++i) p.pre_mat[i] = d->pre_mat[i];
+    for (int i = 0; i < 3; ++i) p.pre_bias[i] = d->pre_bias[i];
+    p.wgt = d->w_kcio; p.bias = d->bias;
+    p.out = to_view(d->out); p.out2 = to_view(d->out2);
+    const long long total = (long long)d->n * d->h * d->w * (d->cout / 4);
+    if ((total + 255) / 256 > 0x7fffffffll) SRMI_FAIL("srmi_conv_first: problem too large");
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, p);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_ca_scale(const float* chansum, int n, int tiles, int c, int cr, int hw,
+                             const float* w1, const float* b1, const float* w2, const float* b2,
+                             float* scale, void* hip_stream) {
+    if (!chansum || !w1 || !b1 || !w2 || !b2 || !scale) SRMI_FAIL("srmi_ca_scale: null pointer");
+    if (n <= 0 || tiles <= 0 || c <= 0 || cr <= 0 || hw <= 0 || c > 4096) SRMI_FAIL("srmi_ca_scale: bad shape");
+    const size_t lds = (size_t)(5 * c + cr) * sizeof(float);
+    hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(256), lds, (hipStream_t)hip_stream, chansum, tiles, c, cr,
+                       1.0f / (float)hw, w1, b1, w2, b2, scale);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_ca_apply(const srmi_tensor_t* y, const srmi_tensor_t* x, const float* scale,
+                             float res_scale, int n, int h, int w, int c,
+                             const srmi_tensor_t* out, const srmi_tensor_t* out2, void* hip_stream) {
+    if (!y || !x || !y->ptr || !x->ptr || !scale || !out) SRMI_FAIL("srmi_ca_apply: null pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 32) SRMI_FAIL("srmi_ca_apply: bad shape");
+    TView o2;
+    o2.ptr = nullptr; o2.img_stride_b = o2.plane_stride_b = 0; o2.dtype = 0; o2.pad = 0;
+    if (out2) o2 = to_view(*out2);
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(ca_apply_kernel, dim3(grid_for(n * hw * (c / 8))), dim3(256), 0, (hipStream_t)hip_stream,
+                       to_view(*y), to_view(*x), scale, res_scale, n, hw, c, to_view(*out), o2);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_channel_sums(const srmi_tensor_t* x, int n, int h, int w, int c, float* sums, void* hip_stream) {
+    if (!x || !x->ptr || !sums) SRMI_FAIL("srmi_channel_sums: null pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 4) SRMI_FAIL("srmi_channel_sums: bad shape");
+    hipStream_t s = (hipStream_t)hip_stream;
+    SRMI_HIP(hipMemsetAsync(sums, 0, (size_t)n * c * sizeof(float), s));
+    const long long hw = (long long)h * w;
+    const int seg = 4096;
+    dim3 grid((unsigned)((hw + seg - 1) / seg), (unsigned)((c / 4 + 15) / 16), (unsigned)n);
+    hipLaunchKernelGGL(channel_sums_kernel, grid, dim3(256), 0, s, to_view(*x), hw, c, sums, seg);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_pixel_shuffle(const srmi_tensor_t* in, const srmi_tensor_t* out, int n, int h, int w,
+                                  int c_in, int r, void* hip_stream) {
+    if (!in || !out || !in->ptr || !out->ptr) SRMI_FAIL("srmi_pixel_shuffle: null pointer");
+    if (in->dtype != out->dtype) SRMI_FAIL("srmi_pixel_shuffle: dtype mismatch");
+    if (r < 2 || r > 4 || c_in % (r * r)) SRMI_FAIL("srmi_pixel_shuffle: bad r=%d / c_in=%d", r, c_in);
+    const int c_out = c_in / (r * r);
+    const int epc = 16 / dtype_size(in->dtype);
+    if (c_out % epc) SRMI_FAIL("srmi_pixel_shuffle: c_out=%d is not a multiple of %d", c_out, epc);
+    const long long total = (long long)n * h * r * w * r * (c_out / epc);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (in->dtype == SRMI_F32)
+        hipLaunchKernelGGL(pixel_shuffle_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, to_view(*in), to_view(*out), n, h, w, c_out, r);
+    else
+        hipLaunchKernelGGL(pixel_shuffle_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s, to_view(*in), to_view(*out), n, h, w, c_out, r);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_nearest_up2(const srmi_tensor_t* in, const srmi_tensor_t* out, int n, int h, int w,
+                                int c, void* hip_stream) {
+    if (!in || !out || !in->ptr || !out->ptr) SRMI_FAIL("srmi_nearest_up2: null pointer");
+    if (in->dtype != out->dtype) SRMI_FAIL("srmi_nearest_up2: dtype mismatch");
+    const int cpb = dtype_cpb(in->dtype);
+    if (c <= 0 || c % cpb) SRMI_FAIL("srmi_nearest_up2: c=%d is not a multiple of %d", c, cpb);
+    const int planes = c / cpb;
+    const long long total = (long long)n * planes * h * 2 * w * 2 * 4;
+    hipLaunchKernelGGL(nearest_up2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)hip_stream,
+                       to_view(*in), to_view(*out), n, h, w, planes);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_nchw_to_planes(const float* in, const srmi_tensor_t* out, int n, int c, int h, int w,
+                                   void* hip_stream) {
+    if (!in || !out || !out->ptr) SRMI_FAIL("srmi_nchw_to_planes: null pointer");
+    const int cpb = dtype_cpb(out->dtype);
+    const int c_pad = (c + cpb - 1) / cpb * cpb;
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(nchw_to_planes_kernel, dim3(grid_for(n * hw * (c_pad / 4))), dim3(256), 0, (hipStream_t)hip_stream,
+                       in, to_view(*out), n, c, c_pad, hw);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_planes_to_nchw(const srmi_tensor_t* in, float* out, int n, int c, int h, int w,
+                                   void* hip_stream) {
+    if (!in || !in->ptr || !out) SRMI_FAIL("srmi_planes_to_nchw: null pointer");
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(planes_to_nchw_kernel, dim3(grid_for(n * hw * ((c + 3) / 4))), dim3(256), 0, (hipStream_t)hip_stream,
+                       to_view(*in), out, n, c, hw);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_resize_bilinear_u8(const uint8_t* in, int in_w, int in_h, uint8_t* out, int out_w,
+                                       int out_h, void* hip_stream) {
+    if (!in || !out) SRMI_FAIL("srmi_resize_bilinear_u8: null pointer");
+    if (in_w <= 0 || in_h <= 0 || out_w <= 0 || out_h <= 0) SRMI_FAIL("srmi_resize_bilinear_u8: bad size");
+    const float xr = (float)in_w / (float)out_w, yr = (float)in_h / (float)out_h;
+    hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3(grid_for((long long)out_w * out_h)), dim3(256), 0,
+                       (hipStream_t)hip_stream, in, in_w, in_h, out, out_w, out_h, xr, yr);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,75 @@
+// Internal declarations shared by the HIP sources of libsrmi355.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/srmi355.h"
+
+namespace srmi {
+
+// ---- error handling ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define SRMI_FAIL(...)                 \
+    do {                               \
+        ::srmi::set_error(__VA_ARGS__); \
+        return -1;                     \
+    } while (0)
+#define SRMI_HIP(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) SRMI_FAIL("%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- device-side tensor view --------------------------------------------------------------------
+// Byte strides; a pixel of one plane is always 64 bytes.
+struct TView {
+    char* ptr;
+    long long img_stride_b;
+    long long plane_stride_b;
+    int dtype;
+    int pad;
+};
+
+static inline int dtype_size(int dt) { return dt == SRMI_F32 ? 4 : 2; }
+static inline int dtype_cpb(int dt) { return dt == SRMI_F32 ? 16 : 32; }  // channels per plane
+
+static inline TView to_view(const srmi_tensor_t& t) {
+    TView v;
+    v.ptr = (char*)t.ptr;
+    v.img_stride_b = (long long)t.img_stride * dtype_size(t.dtype);
+    v.plane_stride_b = (long long)t.plane_stride * dtype_size(t.dtype);
+    v.dtype = t.dtype;
+    v.pad = 0;
+    return v;
+}
+
+constexpr int kTileW = 32;      // pixels per MFMA column block = tile width
+constexpr int kPatchW = kTileW + 2;
+
+// ---- kernel parameter blocks --------------------------------------------------------------------
+struct ConvParams {
+    int n, h, w;          // conv (output) spatial size
+    int ncb;              // input channel blocks (planes of the input dtype)
+    int cout;             // padded to a multiple of the workgroup's cout tile
+    int cout_real;
+    int in_up2;
+    int act;
+    int ps_r, ps_c;       // pixel-shuffle factor and channels after the shuffle
+    int tiles_x, tiles_y;
+    int tail_mode, tail_round;
+    TView in;
+    const char* wpk;
+    const float* bias;
+    float alpha, beta;
+    TView res1, res2, out, out2;
+    float* chansum;
+    void* tail_out;
+    float tail_mat[9];
+    float tail_bias[3];
+    float tail_lo, tail_hi, tail_scale;
+};
+
+}  // namespace srmi

@@ -1,0 +1,375 @@
+// 3x3 convolution as implicit GEMM on the gfx950 matrix cores, with the networks' elementwise
+// tails fused into the epilogue.
+//
+// Work decomposition
+//   workgroup  = 256 threads (4 waves, one per SIMD) -> a spatial tile of (4*MB) rows x 32 columns
+//                of one image and a tile of 32*NB output channels.
+//   wave       = MB consecutive rows of the tile (one row of 32 pixels = one MFMA column block)
+//                x NB blocks of 32 output channels: MB*NB accumulators of 32x32 (f32).
+//   MFMA roles = A operand: weights (rows = output channel), B operand: pixels (columns), so a lane
+//                ends up holding 4 consecutive output channels of ONE pixel per register group and
+//                the epilogue reads residuals / writes results with 8- or 16-byte accesses.
+//
+// Data movement per input-channel block (one 64-byte-per-pixel plane = 32 halves or 16 floats):
+//   weights   : pre-swizzled on the host into exactly the LDS image; copied global -> LDS by LDS-DMA
+//               (global_load_lds, 16 B per lane), no registers involved.
+//   pixels    : (4*MB+2) x 34 halo patch, 16-byte chunks gathered global -> VGPR -> LDS so that
+//               out-of-image chunks become zeros and nearest-x2 upsampling is a pure address map.
+//   both are double buffered: block cb+1 is in flight while block cb feeds the MFMAs.
+// LDS rows are 64 bytes; the 16-byte chunk index is XORed with (row>>2)&3 so that the 16-lane
+// groups of ds_read_b128 touch 16 different bank slots (conflict-free).
+//
+// The kernel is written in bytes: f16, bf16 and f32 differ only in the MFMA issued per pair of
+// 16-byte chunks (one 32x32x16 half MFMA, or four 32x32x2 f32 MFMAs) and in the epilogue casts.
+#include "common.h"
+#include "devutil.h"
+
+namespace srmi {
+
+template <int DT>
+__device__ __forceinline__ void mma_chunk(f32x16& c, const u32x4& wfrag, const u32x4& pfrag) {
+    if constexpr (DT == SRMI_F16) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wfrag),
+                                                   __builtin_bit_cast(f16x8, pfrag), c, 0, 0, 0);
+    } else if constexpr (DT == SRMI_BF16) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag),
+                                                    __builtin_bit_cast(bf16x8, pfrag), c, 0, 0, 0);
+    } else {
+        // whole-vector casts first: bit-casting a single element of a vector reference makes
+        // hipcc (ROCm 7.2) read element 0 for every j
+        const f32x4 wv = __builtin_bit_cast(f32x4, wfrag);
+        const f32x4 pv = __builtin_bit_cast(f32x4, pfrag);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], pv[j], c, 0, 0, 0);
+    }
+}
+
+template <int DT, int MB, int NB>
+__global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
+    constexpr int TH = 4 * MB, PH = TH + 2, PW = kPatchW;
+    constexpr int A_BYTES = PH * PW * 64;
+    constexpr int B_BYTES = 9 * 32 * NB * 64;
+    constexpr int NCH = PH * PW * 4;               // 16-byte chunks of the pixel patch
+    constexpr int NLD = (NCH + 255) / 256;         // chunks per thread
+    constexpr int NPIECE = B_BYTES / 1024;         // 1-KiB LDS-DMA pieces of the weight image
+    constexpr int NPW = (NPIECE + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int x0 = tx * kTileW, y0 = ty * TH;
+    const int ct = blockIdx.y;
+    const int n = blockIdx.z;
+
+    // ---- per-thread gather map of the pixel patch (identical for every channel block) ----------
+    unsigned aoff[NLD];
+    unsigned amask = 0;
+    {
+        const int srcW = p.in_up2 ? (p.w >> 1) : p.w;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            const int pp = i >> 2, cs = i & 3;
+            const int c = cs ^ ((pp >> 2) & 3);
+            const int rho = pp / PW, xi = pp - rho * PW;
+            int gy = y0 - 1 + rho, gx = x0 - 1 + xi;
+            const bool ok = (i < NCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+            if (p.in_up2) { gy >>= 1; gx >>= 1; }
+            aoff[k] = ok ? ((unsigned)(gy * srcW + gx) * 64u + (unsigned)c * 16u) : 0u;
+            amask |= ok ? (1u << k) : 0u;
+        }
+    }
+    const char* in_img = p.in.ptr + (long long)n * p.in.img_stride_b;
+    const char* w_tile = p.wpk + (size_t)ct * p.ncb * B_BYTES;
+
+    u32x4 areg[NLD];
+    auto issue = [&](int cb, int buf) {
+        const char* wsrc = w_tile + (size_t)cb * B_BYTES + lane * 16;
+        char* bdst = smem + 2 * A_BYTES + buf * B_BYTES;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int k = wave + 4 * j;
+            if (k < NPIECE)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wsrc + k * 1024),
+                    (__attribute__((address_space(3))) void*)(bdst + k * 1024), 16, 0, 0);
+        }
+        const char* src = in_img + (long long)cb * p.in.plane_stride_b;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            areg[k] = ((amask >> k) & 1u) ? *(const u32x4*)(src + aoff[k]) : z;
+        }
+    };
+    auto commit = [&](int buf) {
+        char* adst = smem + buf * A_BYTES;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NCH) *(u32x4*)(adst + i * 16) = areg[k];
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int r = 0; r < MB; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][b][i] = 0.f;
+
+    const int lx = lane & 31, lh = lane >> 5;
+    const int p0 = wave * MB * PW + lx;            // LDS pixel index of (first row of this wave, lx)
+    const int bm = (lx >> 2) & 3;                  // weight-row swizzle term (row = 32*k + lx)
+
+    issue(0, 0);
+    commit(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int cb = 0; cb < p.ncb; ++cb) {
+        const int cur = cb & 1;
+        const bool more = cb + 1 < p.ncb;
+        if (more) issue(cb + 1, cur ^ 1);
+
+        const char* Ab = smem + cur * A_BYTES;
+        const char* Bb = smem + 2 * A_BYTES + cur * B_BYTES + lx * 64;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c = 2 * s + lh;
+                u32x4 wf[3][NB];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        wf[dy][b] = *(const u32x4*)(Bb + ((dy * 3 + dx) * 32 * NB + b * 32) * 64 +
+                                                    ((c ^ bm) << 4));
+#pragma unroll
+                for (int rho = 0; rho < MB + 2; ++rho) {
+                    const int pp = p0 + rho * PW + dx;
+                    const u32x4 pf = *(const u32x4*)(Ab + pp * 64 + (((c ^ (pp >> 2)) & 3) << 4));
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = rho - dy;
+                        if (r >= 0 && r < MB) {
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) mma_chunk<DT>(acc[r][b], wf[dy][b], pf);
+                        }
+                    }
+                }
+            }
+        }
+
+        if (more) commit(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    const int x = x0 + lx;
+    float csum[NB][16];
+    if (p.chansum) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) csum[b][i] = 0.f;
+    }
+    const int ow = p.w * p.ps_r;
+#pragma unroll
+    for (int r = 0; r < MB; ++r) {
+        const int y = y0 + wave * MB + r;
+        const bool inside = (y < p.h) && (x < p.w);
+        const long long pix = (long long)y * p.w + x;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cq = (ct * NB + b) * 32 + 8 * g + 4 * lh;
+                float v[4];
+                {
+                    const f32x4 bias = *(const f32x4*)(p.bias + cq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[r][b][4 * g + j] + bias[j];
+                }
+                if (p.act == SRMI_ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                } else if (p.act == SRMI_ACT_LRELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] >= 0.f ? v[j] : v[j] * 0.2f;
+                }
+                const bool live = inside && cq < p.cout_real;
+                if (p.res1.ptr && live) {
+                    float q[4];
+                    load4(p.res1, n, pix, cq, q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * p.alpha + q[j];
+                }
+                if (p.res2.ptr && live) {
+                    float q[4];
+                    load4(p.res2, n, pix, cq, q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * p.beta + q[j];
+                }
+                if (p.out.ptr && live) {
+                    if (p.ps_r == 1) {
+                        store4(p.out, n, pix, cq, v);
+                    } else {
+                        const int ij = cq / p.ps_c, cc = cq - ij * p.ps_c;
+                        const int oy = y * p.ps_r + ij / p.ps_r, ox = x * p.ps_r + ij % p.ps_r;
+                        store4(p.out, n, (long long)oy * ow + ox, cc, v);
+                    }
+                }
+                if (p.out2.ptr && live) store4(p.out2, n, pix, cq, v);
+                if (p.chansum) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) csum[b][4 * g + j] += live ? v[j] : 0.f;
+                }
+                if (p.tail_mode != SRMI_TAIL_NONE && b == 0 && g == 0 && lh == 0 && inside && ct == 0) {
+                    float rgb[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        rgb[k] = p.tail_mat[3 * k] * v[0] + p.tail_mat[3 * k + 1] * v[1] +
+                                 p.tail_mat[3 * k + 2] * v[2] + p.tail_bias[k];
+                    if (p.tail_mode == SRMI_TAIL_F32_NCHW) {
+                        float* o = (float*)p.tail_out + (long long)n * 3 * p.h * p.w + pix;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) o[(long long)k * p.h * p.w] = rgb[k];
+                    } else {
+                        unsigned char* o = (unsigned char*)p.tail_out + ((long long)n * p.h * p.w + pix) * 3;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            o[k] = to_u8(rgb[k], p.tail_lo, p.tail_hi, p.tail_scale, p.tail_round);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (p.chansum) {
+        // deterministic tile sums: lanes -> wave (xor shuffles inside each 32-lane half), waves -> LDS
+        float* red = (float*)smem;  // [4 waves][32*NB]; the pixel patch is no longer needed
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float s = csum[b][i];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m);
+                if (lx == 0) red[wave * 32 * NB + b * 32 + 8 * (i >> 2) + 4 * lh + (i & 3)] = s;
+            }
+        __syncthreads();
+        if (tid < 32 * NB) {
+            const float s = (red[tid] + red[32 * NB + tid]) + (red[2 * 32 * NB + tid] + red[3 * 32 * NB + tid]);
+            const int cq = ct * 32 * NB + tid;
+            if (cq < p.cout_real)
+                p.chansum[((long long)n * (p.tiles_x * p.tiles_y) + tile) * p.cout_real + cq] = s;
+        }
+    }
+}
+
+// ---- host launcher --------------------------------------------------------------------------------
+template <int DT, int MB, int NB>
+static int launch(const ConvParams& p, hipStream_t stream) {
+    constexpr int TH = 4 * MB;
+    constexpr size_t lds = 2 * ((TH + 2) * kPatchW * 64 + 9 * 32 * NB * 64);
+    static bool configured = false;
+    if (!configured) {
+        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y, p.cout / (32 * NB), p.n);
+    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB>), grid, dim3(256), lds, stream, p);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int DT>
+static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
+    if (nb == 1) {
+        if (mb == 2) return launch<DT, 2, 1>(p, s);
+        if (mb == 3) return launch<DT, 3, 1>(p, s);
+        return launch<DT, 4, 1>(p, s);
+    }
+    if (mb == 2) return launch<DT, 2, 2>(p, s);
+    if (mb == 3) return launch<DT, 3, 2>(p, s);
+    return launch<DT, 4, 2>(p, s);
+}
+
+static int default_rows_per_wave() { return 2; }
+
+}  // namespace srmi
+
+using namespace srmi;
+
+extern "C" int srmi_conv3x3_tiles(int h, int w, int rows_per_wave) {
+    const int mb = rows_per_wave ? rows_per_wave : default_rows_per_wave();
+    const int th = 4 * mb;
+    return ((w + kTileW - 1) / kTileW) * ((h + th - 1) / th);
+}
+
+extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
+    if (!d) SRMI_FAIL("srmi_conv3x3: null descriptor");
+    if (d->dtype != SRMI_F32 && d->dtype != SRMI_F16 && d->dtype != SRMI_BF16)
+        SRMI_FAIL("srmi_conv3x3: bad dtype %d", d->dtype);
+    const int cpb = dtype_cpb(d->dtype);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0) SRMI_FAIL("srmi_conv3x3: bad shape n=%d h=%d w=%d", d->n, d->h, d->w);
+    if (d->cin <= 0 || d->cin % cpb) SRMI_FAIL("srmi_conv3x3: cin=%d is not a multiple of %d", d->cin, cpb);
+    if (!d->in.ptr || d->in.dtype != d->dtype) SRMI_FAIL("srmi_conv3x3: input tensor missing or of another dtype");
+    if (!d->wpk || !d->bias) SRMI_FAIL("srmi_conv3x3: missing weights or bias");
+    if (d->cout_tile != 32 && d->cout_tile != 64) SRMI_FAIL("srmi_conv3x3: cout_tile must be 32 or 64");
+    const int mb = d->rows_per_wave ? d->rows_per_wave : default_rows_per_wave();
+    if (mb < 2 || mb > 4) SRMI_FAIL("srmi_conv3x3: rows_per_wave must be 2, 3 or 4");
+    const bool tail = d->tail_mode != SRMI_TAIL_NONE;
+    if (tail) {
+        if (d->cout != 3 || !d->tail_out) SRMI_FAIL("srmi_conv3x3: an RGB tail needs cout == 3 and tail_out");
+        if (d->out.ptr || d->out2.ptr || d->chansum || d->ps_r > 1)
+            SRMI_FAIL("srmi_conv3x3: an RGB tail excludes plane outputs");
+    } else {
+        if (d->cout <= 0 || d->cout % d->cout_tile) SRMI_FAIL("srmi_conv3x3: cout=%d is not a multiple of cout_tile=%d", d->cout, d->cout_tile);
+        if (!d->out.ptr && !d->out2.ptr) SRMI_FAIL("srmi_conv3x3: no output tensor");
+    }
+    const int r = d->ps_r <= 1 ? 1 : d->ps_r;
+    if (r > 3) SRMI_FAIL("srmi_conv3x3: ps_r must be 1, 2 or 3");
+    if (r > 1 && (d->cout % (r * r * 32) || d->out2.ptr || d->res1.ptr || d->res2.ptr))
+        SRMI_FAIL("srmi_conv3x3: pixel-shuffle store needs cout %% (32*r*r) == 0 and no residual/out2");
+    if (d->in_up2 && ((d->h | d->w) & 1)) SRMI_FAIL("srmi_conv3x3: in_up2 needs even h and w");
+    if ((long long)d->h * d->w * 64 * r * r >= (1ll << 32)) SRMI_FAIL("srmi_conv3x3: plane larger than 4 GiB");
+
+    ConvParams p;
+    p.n = d->n; p.h = d->h; p.w = d->w;
+    p.ncb = d->cin / cpb;
+    p.cout_real = d->cout;
+    p.cout = (d->cout + d->cout_tile - 1) / d->cout_tile * d->cout_tile;
+    p.in_up2 = d->in_up2 ? 1 : 0;
+    p.act = d->act;
+    p.ps_r = r;
+    p.ps_c = d->cout / (r * r);
+    p.tiles_x = (d->w + kTileW - 1) / kTileW;
+    p.tiles_y = (d->h + 4 * mb - 1) / (4 * mb);
+    p.tail_mode = d->tail_mode; p.tail_round = d->tail_round;
+    p.in = to_view(d->in);
+    p.wpk = (const char*)d->wpk; p.bias = d->bias;
+    p.alpha = d->alpha; p.beta = d->beta;
+    p.res1 = to_view(d->res1); p.res2 = to_view(d->res2);
+    p.out = to_view(d->out); p.out2 = to_view(d->out2);
+    p.chansum = d->chansum;
+    p.tail_out = d->tail_out;
+    for (int i = 0; i < 9; ++i) p.tail_mat[i] = d->tail_mat[i];
+    for (int i = 0; i < 3; ++i) p.tail_bias[i] = d->tail_bias[i];
+    p.tail_lo = d->tail_lo; p.tail_hi = d->tail_hi; p.tail_scale = d->tail_scale;
+
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int nb = d->cout_tile / 32;
+    if (d->dtype == SRMI_F16) return launch_dt<SRMI_F16>(p, mb, nb, s);
+    if (d->dtype == SRMI_BF16) return launch_dt<SRMI_BF16>(p, mb, nb, s);
+    return launch_dt<SRMI_F32>(p, mb, nb, s);
+}

@@ -1,0 +1,64 @@
+// Device-side helpers shared by the kernels: vector typedefs and 4-channel accessors on plane
+// tensors.
+#pragma once
+#include "common.h"
+
+namespace srmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---- 4-channel accessors on plane tensors (runtime dtype, wave-uniform branches) -----------------
+__device__ __forceinline__ char* chan_addr(const TView& t, int n, long long pix, int c) {
+    char* base = t.ptr + (long long)n * t.img_stride_b;
+    if (t.dtype == SRMI_F32) return base + (long long)(c >> 4) * t.plane_stride_b + pix * 64 + (c & 15) * 4;
+    return base + (long long)(c >> 5) * t.plane_stride_b + pix * 64 + (c & 31) * 2;
+}
+
+__device__ __forceinline__ void load4(const TView& t, int n, long long pix, int c, float (&v)[4]) {
+    const char* a = chan_addr(t, n, pix, c);
+    if (t.dtype == SRMI_F32) {
+        f32x4 x = *(const f32x4*)a;
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    } else if (t.dtype == SRMI_F16) {
+        f16x4 x = *(const f16x4*)a;
+        v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3];
+    } else {
+        bf16x4 x = *(const bf16x4*)a;
+        v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3];
+    }
+}
+
+__device__ __forceinline__ void store4(const TView& t, int n, long long pix, int c, const float (&v)[4]) {
+    char* a = chan_addr(t, n, pix, c);
+    if (t.dtype == SRMI_F32) {
+        f32x4 x = {v[0], v[1], v[2], v[3]};
+        *(f32x4*)a = x;
+    } else if (t.dtype == SRMI_F16) {
+        f16x4 x = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *(f16x4*)a = x;
+    } else {
+        bf16x4 x = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *(bf16x4*)a = x;
+    }
+}
+
+// clamp -> scale -> round to the u8 grid; separate roundings for the multiply and the +0.5 (no
+// fused multiply-add), as the scalar host code of the runners computes them.
+__device__ __forceinline__ unsigned char to_u8(float v, float lo, float hi, float scale, int mode) {
+#pragma clang fp contract(off)
+    float t = fminf(fmaxf(v, lo), hi) * scale;
+    if (mode == SRMI_ROUND_HALF_EVEN) t = rintf(t);
+    else if (mode == SRMI_ROUND_HALF_UP) t = floorf(t + 0.5f);
+    else t = truncf(t);
+    return (unsigned char)t;
+}
+
+
+}  // namespace srmi

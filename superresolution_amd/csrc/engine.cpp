@@ -1,0 +1,817 @@
+// Whole-network executor: builds the fused layer sequence of EDSR / RCAN / RRDBNet from the
+// reference's state_dict and runs forward(img) as a chain of kernel launches on one HIP stream.
+//
+// Fused execution plans (one line = one launch):
+//   RRDBNet (realesrgan_model.py:96-123)
+//     conv_first(img) -> D[0:nf] and F
+//     per RRDB, per RDB: conv1..4 write their grow_ch channels into slices of the dense buffer D
+//       (this is torch.cat, realesrgan_model.py:27-30), conv5: *0.2 + x [(...)*0.2 + R on rdb3]
+//       -> first nf channels of the OTHER dense buffer (ping-pong, so halo reads never race)
+//     conv_body + F ; conv_up1 / conv_up2 read through a nearest-x2 address map ; conv_hr ;
+//     conv_last -> RGB tail (f32 NCHW, or clamp*255 round -> u8)
+//   EDSR (edsr_model.py:114-124)
+//     head(img, MeanShift in the loader) ; 32 x [conv+ReLU ; conv*res_scale + x] ; conv + head ;
+//     upsampler convs with PixelShuffle stores ; tail conv -> RGB tail with add_mean
+//   RCAN (rcan_model.py:149-159)
+//     as EDSR, with per RCAB: conv+ReLU ; conv (+ per-tile channel sums) ; squeeze/excite ;
+//     x + res_scale * y * s ; and per group: conv + group input.
+//
+// Precision: activations are stored in the compute dtype; with trunk_f32 (half dtypes) every
+// tensor that is only ever consumed as a residual is additionally kept in f32, so rounding to
+// half happens once per convolution input and never accumulates along the residual chain.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace srmi {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool set = false;
+};
+
+struct ConvW {
+    void* wpk = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cin = 0, cout_tile = 0, ps_r = 1;
+};
+
+struct CaW {
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+};
+
+struct Buf {
+    char* ptr = nullptr;
+    int dtype = 0, c = 0, h = 0, w = 0;
+};
+
+static inline int64_t numel(const std::vector<int64_t>& s) {
+    int64_t n = 1;
+    for (auto v : s) n *= v;
+    return n;
+}
+
+}  // namespace srmi
+
+using namespace srmi;
+
+struct srmi_model {
+    srmi_model_desc_t d;
+    std::vector<std::string> keys;
+    std::map<std::string, HostTensor> tensors;
+    bool finalized = false;
+
+    std::map<std::string, ConvW> convs;
+    std::vector<CaW> cas;
+    float* first_w = nullptr;  // [27][nf]
+    float* first_b = nullptr;
+    float sub_mat[9], sub_bias[3], add_mat[9], add_bias[3];
+    std::vector<void*> dev_allocs;
+
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int sweep = 1;
+    int mb_override = 0;
+
+    int cdt() const { return d.dtype; }
+    int tdt() const { return (d.dtype == SRMI_F32 || d.trunk_f32) ? SRMI_F32 : d.dtype; }  // trunk dtype
+    bool split_trunk() const { return tdt() != cdt(); }
+};
+
+namespace srmi {
+
+static void expect(srmi_model* m, const std::string& key, std::vector<int64_t> shape) {
+    m->keys.push_back(key);
+    HostTensor t;
+    t.shape = std::move(shape);
+    m->tensors[key] = std::move(t);
+}
+
+static void expect_conv(srmi_model* m, const std::string& name, int cout, int cin, int k) {
+    expect(m, name + ".weight", {cout, cin, k, k});
+    expect(m, name + ".bias", {cout});
+}
+
+static int upsampler_stages(int scale, int* r) {
+    if (scale == 3) { *r = 3; return 1; }
+    *r = 2;
+    int n = 0;
+    while ((1 << n) < scale) ++n;
+    return n;
+}
+
+static int build_keys(srmi_model* m) {
+    const auto& d = m->d;
+    const int nf = d.n_feats;
+    if (d.arch == SRMI_ARCH_RRDBNET) {
+        // registration order of RRDBNet.__init__ (realesrgan_model.py:67-94)
+        const int gc = d.grow_ch;
+        expect_conv(m, "conv_first", nf, 3, 3);
+        for (int i = 0; i < d.n_blocks; ++i)
+            for (int r = 1; r <= 3; ++r)
+                for (int j = 1; j <= 5; ++j) {
+                    char name[96];
+                    snprintf(name, sizeof(name), "body.%d.rdb%d.conv%d", i, r, j);
+                    expect_conv(m, name, j == 5 ? nf : gc, nf + (j - 1) * gc, 3);
+                }
+        expect_conv(m, "conv_body", nf, nf, 3);
+        expect_conv(m, "conv_up1", nf, nf, 3);
+        if (d.scale == 4) expect_conv(m, "conv_up2", nf, nf, 3);
+        expect_conv(m, "conv_hr", nf, nf, 3);
+        expect_conv(m, "conv_last", 3, nf, 3);
+        return 0;
+    }
+    // EDSR.__init__ (edsr_model.py:82-112) / RCAN.__init__ (rcan_model.py:123-147)
+    if (d.with_meanshift) {
+        expect_conv(m, "sub_mean", 3, 3, 1);
+        expect_conv(m, "add_mean", 3, 3, 1);
+    }
+    expect_conv(m, "head.0", nf, 3, 3);
+    char name[128];
+    if (d.arch == SRMI_ARCH_EDSR) {
+        for (int i = 0; i < d.n_blocks; ++i) {
+            snprintf(name, sizeof(name), "body.%d.body.0", i);
+            expect_conv(m, name, nf, nf, 3);
+            snprintf(name, sizeof(name), "body.%d.body.2", i);
+            expect_conv(m, name, nf, nf, 3);
+        }
+        snprintf(name, sizeof(name), "body.%d", d.n_blocks);
+        expect_conv(m, name, nf, nf, 3);
+    } else {
+        const int cr = nf / d.reduction;
+        for (int g = 0; g < d.n_groups; ++g) {
+            for (int b = 0; b < d.n_blocks; ++b) {
+                snprintf(name, sizeof(name), "body.%d.body.%d.body.0", g, b);
+                expect_conv(m, name, nf, nf, 3);
+                snprintf(name, sizeof(name), "body.%d.body.%d.body.2", g, b);
+                expect_conv(m, name, nf, nf, 3);
+                snprintf(name, sizeof(name), "body.%d.body.%d.body.3.conv_du.0", g, b);
+                expect_conv(m, name, cr, nf, 1);
+                snprintf(name, sizeof(name), "body.%d.body.%d.body.3.conv_du.2", g, b);
+                expect_conv(m, name, nf, cr, 1);
+            }
+            snprintf(name, sizeof(name), "body.%d.body.%d", g, d.n_blocks);
+            expect_conv(m, name, nf, nf, 3);
+        }
+        snprintf(name, sizeof(name), "body.%d", d.n_groups);
+        expect_conv(m, name, nf, nf, 3);
+    }
+    int r;
+    const int stages = upsampler_stages(d.scale, &r);
+    for (int s = 0; s < stages; ++s) {
+        snprintf(name, sizeof(name), "tail.0.%d", 2 * s);
+        expect_conv(m, name, r * r * nf, nf, 3);
+    }
+    expect_conv(m, "tail.1", 3, nf, 3);
+    return 0;
+}
+
+static int dev_upload(srmi_model* m, const void* host, size_t bytes, void** out) {
+    void* p = nullptr;
+    SRMI_HIP(hipMalloc(&p, bytes));
+    m->dev_allocs.push_back(p);
+    SRMI_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+
+static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
+    const HostTensor& w = m->tensors[name + ".weight"];
+    const HostTensor& b = m->tensors[name + ".bias"];
+    ConvW cw;
+    cw.cout = (int)w.shape[0];
+    cw.cin = (int)w.shape[1];
+    cw.cout_tile = cw.cout <= 32 ? 32 : 64;
+    cw.ps_r = ps_r;
+    int nbias = 0;
+    const size_t bytes = srmi_pack_conv3x3_bytes(m->cdt(), cw.cout, cw.cin, cw.cout_tile, &nbias);
+    if (!bytes) SRMI_FAIL("%s: unsupported conv shape [%d,%d,3,3] for this dtype", name.c_str(), cw.cout, cw.cin);
+    std::vector<char> wp(bytes);
+    std::vector<float> bp(nbias);
+    if (srmi_pack_conv3x3(m->cdt(), cw.cout, cw.cin, cw.cout_tile, ps_r, w.data.data(), b.data.data(), wp.data(), bp.data()))
+        return -1;
+    if (dev_upload(m, wp.data(), bytes, &cw.wpk)) return -1;
+    if (dev_upload(m, bp.data(), nbias * sizeof(float), (void**)&cw.bias)) return -1;
+    m->convs[name] = cw;
+    return 0;
+}
+
+static int upload_first(srmi_model* m, const std::string& name) {
+    const HostTensor& w = m->tensors[name + ".weight"];  // [nf][3][3][3]
+    const HostTensor& b = m->tensors[name + ".bias"];
+    const int nf = (int)w.shape[0];
+    std::vector<float> t((size_t)27 * nf);
+    for (int o = 0; o < nf; ++o)
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 9; ++k) t[(size_t)(k * 3 + c) * nf + o] = w.data[((size_t)o * 3 + c) * 9 + k];
+    if (dev_upload(m, t.data(), t.size() * sizeof(float), (void**)&m->first_w)) return -1;
+    return dev_upload(m, b.data.data(), nf * sizeof(float), (void**)&m->first_b);
+}
+
+// ---- workspace arena ---------------------------------------------------------------------------
+struct Arena {
+    size_t off = 0;
+    char* base = nullptr;
+    int ns = 1;
+    Buf take(int c, int h, int w, int dtype) {
+        Buf b;
+        b.dtype = dtype; b.c = c; b.h = h; b.w = w;
+        const size_t planes = (size_t)(c + dtype_cpb(dtype) - 1) / dtype_cpb(dtype);
+        b.ptr = base ? base + off : nullptr;
+        off += ((size_t)ns * planes * h * w * 64 + 255) & ~(size_t)255;
+        return b;
+    }
+    float* take_floats(size_t n) {
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += (n * sizeof(float) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+static srmi_tensor_t tv(const Buf& b, int c0 = 0) {
+    srmi_tensor_t t;
+    memset(&t, 0, sizeof(t));
+    if (!b.ptr) return t;
+    const int cpb = dtype_cpb(b.dtype);
+    const int64_t plane = (int64_t)b.h * b.w * cpb;
+    t.ptr = b.ptr + (size_t)(c0 / cpb) * plane * dtype_size(b.dtype);
+    t.plane_stride = plane;
+    t.img_stride = plane * ((b.c + cpb - 1) / cpb);
+    t.dtype = b.dtype;
+    return t;
+}
+
+static int pick_rows_per_wave(const srmi_model* m, int h, int w, int cout, int cout_tile, int ns) {
+    if (m->mb_override) return m->mb_override;
+    // estimated time ~ (rounds of 256 workgroups) x (rows per workgroup) x (per-row cost, lower for
+    // taller wave tiles because weight fragments and LDS pixel rows are reused more)
+    const double rel[5] = {0, 0, 1.0, 0.93, 0.90};
+    int best = 2;
+    double best_cost = 1e30;
+    for (int mb = 2; mb <= 4; ++mb) {
+        const long long tiles = (long long)((w + kTileW - 1) / kTileW) * ((h + 4 * mb - 1) / (4 * mb)) *
+                                ((cout + cout_tile - 1) / cout_tile) * ns;
+        const long long rounds = (tiles + 255) / 256;
+        // large grids: fractional rounds matter less; blend towards the smooth estimate
+        const double eff_rounds = tiles >= 256 * 8 ? (double)tiles / 256.0 : (double)rounds;
+        const double cost = eff_rounds * 4 * mb * rel[mb];
+        if (cost < best_cost) { best_cost = cost; best = mb; }
+    }
+    return best;
+}
+
+struct Exec {
+    srmi_model* m;
+    hipStream_t stream;
+    int ns;  // images in this sweep
+
+    int conv(const std::string& name, const srmi_tensor_t& in, int h, int w, int act, bool up2,
+             float alpha, const srmi_tensor_t* res1, float beta, const srmi_tensor_t* res2,
+             const srmi_tensor_t* out, const srmi_tensor_t* out2, float* chansum = nullptr, int force_mb = 0) {
+        auto it = m->convs.find(name);
+        if (it == m->convs.end()) SRMI_FAIL("internal: conv '%s' not uploaded", name.c_str());
+        const ConvW& cw = it->second;
+        srmi_conv_desc_t d;
+        memset(&d, 0, sizeof(d));
+        d.dtype = m->cdt();
+        d.n = ns; d.h = h; d.w = w;
+        d.cin = cw.cin; d.cout = cw.cout;
+        d.in_up2 = up2; d.act = act; d.ps_r = cw.ps_r; d.cout_tile = cw.cout_tile;
+        d.rows_per_wave = force_mb ? force_mb : pick_rows_per_wave(m, h, w, cw.cout, cw.cout_tile, ns);
+        d.in = in;
+        d.wpk = cw.wpk; d.bias = cw.bias;
+        d.alpha = alpha; d.beta = beta;
+        if (res1) d.res1 = *res1;
+        if (res2) d.res2 = *res2;
+        if (out) d.out = *out;
+        if (out2) d.out2 = *out2;
+        d.chansum = chansum;
+        return srmi_conv3x3(&d, stream);
+    }
+
+    int tail(const std::string& name, const srmi_tensor_t& in, int h, int w, int mode, void* dst,
+             const float* mat, const float* bias, float lo, float hi, float scale, int round) {
+        const ConvW& cw = m->convs[name];
+        srmi_conv_desc_t d;
+        memset(&d, 0, sizeof(d));
+        d.dtype = m->cdt();
+        d.n = ns; d.h = h; d.w = w;
+        d.cin = cw.cin; d.cout = 3;
+        d.ps_r = 1; d.cout_tile = cw.cout_tile;
+        d.rows_per_wave = pick_rows_per_wave(m, h, w, 3, cw.cout_tile, ns);
+        d.in = in;
+        d.wpk = cw.wpk; d.bias = cw.bias;
+        d.alpha = d.beta = 1.f;
+        d.tail_mode = mode;
+        d.tail_out = dst;
+        for (int i = 0; i < 9; ++i) d.tail_mat[i] = mat[i];
+        for (int i = 0; i < 3; ++i) d.tail_bias[i] = bias[i];
+        d.tail_lo = lo; d.tail_hi = hi; d.tail_scale = scale; d.tail_round = round;
+        return srmi_conv3x3(&d, stream);
+    }
+
+    int first(const void* in, int in_kind, int h, int w, const float* mat, const float* bias,
+              const srmi_tensor_t* out, const srmi_tensor_t* out2) {
+        srmi_conv_first_desc_t d;
+        memset(&d, 0, sizeof(d));
+        d.n = ns; d.h = h; d.w = w; d.cout = m->d.n_feats;
+        d.in_kind = in_kind;
+        d.in = in;
+        for (int i = 0; i < 9; ++i) d.pre_mat[i] = mat[i];
+        for (int i = 0; i < 3; ++i) d.pre_bias[i] = bias[i];
+        d.w_kcio = m->first_w; d.bias = m->first_b;
+        if (out) d.out = *out;
+        if (out2) d.out2 = *out2;
+        return srmi_conv_first(&d, stream);
+    }
+};
+
+struct IoSpec {
+    int in_kind;            // SRMI_IN_*
+    const void* in;
+    int tail_mode;          // SRMI_TAIL_*
+    void* out;
+    float pre_mat[9], pre_bias[3];
+    float post_mat[9], post_bias[3];
+    float lo, hi, scale;
+    int round;
+};
+
+static const float kIdentity[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+
+// The plan functions are written once and run in two modes: with a null arena base they only
+// measure the workspace; with a real base they launch.
+static int run_rrdbnet(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, int w) {
+    const auto& d = m->d;
+    const int nf = d.n_feats, gc = d.grow_ch, T = m->cdt(), TR = m->tdt();
+    const bool split = m->split_trunk();
+    Buf D[2] = {A.take(nf + 4 * gc, h, w, T), A.take(nf + 4 * gc, h, w, T)};
+    Buf R[2] = {A.take(nf, h, w, TR), A.take(nf, h, w, TR)};
+    Buf X[2];
+    if (split) { X[0] = A.take(nf, h, w, TR); X[1] = A.take(nf, h, w, TR); }
+    Buf F = A.take(nf, h, w, TR);
+    const int up = d.scale == 4 ? 2 : 1;
+    Buf U1 = A.take(nf, 2 * h, 2 * w, T);
+    Buf U2, U3;
+    const int hh = h * d.scale, ww = w * d.scale;
+    if (up == 2) U2 = A.take(nf, hh, ww, T);
+    U3 = A.take(nf, hh, ww, T);
+    if (!ex) return 0;
+
+    // conv_first -> D0[0:nf] (conv input of the first RDB) and F (kept for the long skip);
+    // F doubles as R of the first RRDB.
+    {
+        srmi_tensor_t o = tv(D[0]), o2 = tv(F);
+        if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
+    }
+    int k = 0;  // dense buffer holding the current trunk in channels [0, nf)
+    char name[96];
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const Buf& Rin = i == 0 ? F : R[i & 1];
+        for (int r = 1; r <= 3; ++r) {
+            const srmi_tensor_t in = tv(D[k]);
+            for (int j = 1; j <= 4; ++j) {
+                snprintf(name, sizeof(name), "body.%d.rdb%d.conv%d", i, r, j);
+                const srmi_tensor_t o = tv(D[k], nf + (j - 1) * gc);
+                if (ex->conv(name, in, h, w, SRMI_ACT_LRELU, false, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+            }
+            snprintf(name, sizeof(name), "body.%d.rdb%d.conv5", i, r);
+            // residual x of this RDB: the RRDB input for rdb1, else the previous RDB's output
+            srmi_tensor_t res1;
+            if (r == 1) res1 = tv(Rin);
+            else res1 = split ? tv(X[r & 1]) : tv(D[k]);
+            const srmi_tensor_t o = tv(D[k ^ 1]);
+            if (r < 3) {
+                srmi_tensor_t o2 = split ? tv(X[(r + 1) & 1]) : srmi_tensor_t{};
+                if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 0.2f, &res1, 1.f, nullptr, &o, split ? &o2 : nullptr)) return -1;
+            } else {
+                const srmi_tensor_t res2 = tv(Rin);
+                const srmi_tensor_t o2 = tv(R[(i + 1) & 1]);
+                if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 0.2f, &res1, 0.2f, &res2, &o, &o2)) return -1;
+            }
+            k ^= 1;
+        }
+    }
+    // conv_body + F -> feat, stored in the now-free other dense buffer
+    Buf FE = D[k ^ 1];
+    FE.c = nf;
+    {
+        const srmi_tensor_t in = tv(D[k]), res = tv(F), o = tv(FE);
+        if (ex->conv("conv_body", in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o, nullptr)) return -1;
+    }
+    {
+        const srmi_tensor_t in = tv(FE), o = tv(U1);
+        if (ex->conv("conv_up1", in, 2 * h, 2 * w, SRMI_ACT_LRELU, true, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+    }
+    Buf last = U1;
+    if (up == 2) {
+        const srmi_tensor_t in = tv(U1), o = tv(U2);
+        if (ex->conv("conv_up2", in, hh, ww, SRMI_ACT_LRELU, true, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+        last = U2;
+    }
+    {
+        const srmi_tensor_t in = tv(last), o = tv(U3);
+        if (ex->conv("conv_hr", in, hh, ww, SRMI_ACT_LRELU, false, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+    }
+    return ex->tail("conv_last", tv(U3), hh, ww, io->tail_mode, io->out, io->post_mat, io->post_bias,
+                    io->lo, io->hi, io->scale, io->round);
+}
+
+// Upsampler + tail conv shared by EDSR and RCAN (edsr_model.py:50-77,105-108).
+static int run_tail_stages(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, Buf cur, int h, int w) {
+    const auto& d = m->d;
+    int r;
+    const int stages = upsampler_stages(d.scale, &r);
+    char name[64];
+    int ch = h, cw = w;
+    for (int s = 0; s < stages; ++s) {
+        Buf nxt = A.take(d.n_feats, ch * r, cw * r, m->cdt());
+        if (ex) {
+            snprintf(name, sizeof(name), "tail.0.%d", 2 * s);
+            const srmi_tensor_t in = tv(cur), o = tv(nxt);
+            if (ex->conv(name, in, ch, cw, SRMI_ACT_NONE, false, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+        }
+        cur = nxt;
+        ch *= r; cw *= r;
+    }
+    if (!ex) return 0;
+    return ex->tail("tail.1", tv(cur), ch, cw, io->tail_mode, io->out, io->post_mat, io->post_bias,
+                    io->lo, io->hi, io->scale, io->round);
+}
+
+static int run_edsr(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, int w) {
+    const auto& d = m->d;
+    const int nf = d.n_feats, T = m->cdt(), TR = m->tdt();
+    const bool split = m->split_trunk();
+    Buf XT[2] = {A.take(nf, h, w, T), A.take(nf, h, w, T)};
+    Buf XR[2];
+    if (split) { XR[0] = A.take(nf, h, w, TR); XR[1] = A.take(nf, h, w, TR); }
+    Buf Tm = A.take(nf, h, w, T);
+    Buf H = A.take(nf, h, w, TR);
+    if (ex) {
+        srmi_tensor_t o = tv(XT[0]), o2 = tv(H);
+        if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
+        char name[64];
+        int k = 0;
+        for (int i = 0; i < d.n_blocks; ++i) {
+            snprintf(name, sizeof(name), "body.%d.body.0", i);
+            const srmi_tensor_t in = tv(XT[k]), t = tv(Tm);
+            if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr)) return -1;
+            snprintf(name, sizeof(name), "body.%d.body.2", i);
+            // residual: trunk value before this block (edsr_model.py:44-47)
+            srmi_tensor_t res = split ? (i == 0 ? tv(H) : tv(XR[(i - 1) & 1])) : tv(XT[k]);
+            const srmi_tensor_t o1 = tv(XT[k ^ 1]);
+            srmi_tensor_t o2b = split ? tv(XR[i & 1]) : srmi_tensor_t{};
+            if (ex->conv(name, t, h, w, SRMI_ACT_NONE, false, d.res_scale, &res, 1.f, nullptr, &o1, split ? &o2b : nullptr)) return -1;
+            k ^= 1;
+        }
+        snprintf(name, sizeof(name), "body.%d", d.n_blocks);
+        const srmi_tensor_t in = tv(XT[k]), res = tv(H), o1 = tv(XT[k ^ 1]);
+        if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, nullptr)) return -1;
+        return run_tail_stages(m, A, ex, io, XT[k ^ 1], h, w);
+    }
+    return run_tail_stages(m, A, nullptr, io, XT[0], h, w);
+}
+
+static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, int w) {
+    const auto& d = m->d;
+    const int nf = d.n_feats, T = m->cdt(), TR = m->tdt();
+    const bool split = m->split_trunk();
+    const int cr = nf / d.reduction;
+    Buf XT[2] = {A.take(nf, h, w, T), A.take(nf, h, w, T)};
+    Buf XR[2];
+    if (split) { XR[0] = A.take(nf, h, w, TR); XR[1] = A.take(nf, h, w, TR); }
+    Buf Tm = A.take(nf, h, w, T);
+    Buf Y = A.take(nf, h, w, T);
+    Buf H = A.take(nf, h, w, TR);
+    Buf GI[2] = {A.take(nf, h, w, TR), A.take(nf, h, w, TR)};
+    const int ns = A.ns;
+    const int max_tiles = srmi_conv3x3_tiles(h, w, 2);
+    float* chansum = A.take_floats((size_t)ns * max_tiles * nf);
+    float* scale = A.take_floats((size_t)ns * nf);
+    if (ex) {
+        srmi_tensor_t o = tv(XT[0]), o2 = tv(H);
+        if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
+        char name[96];
+        int k = 0;    // XT[k] holds the trunk in the compute dtype
+        int kr = 0;   // XR[kr] holds it in the trunk dtype (split mode), when trunk_in_xr
+        bool trunk_in_xr = false;
+        int ca_index = 0;
+        for (int g = 0; g < d.n_groups; ++g) {
+            const Buf& Gin = g == 0 ? H : GI[g & 1];
+            for (int b = 0; b < d.n_blocks; ++b) {
+                snprintf(name, sizeof(name), "body.%d.body.%d.body.0", g, b);
+                const srmi_tensor_t in = tv(XT[k]), t = tv(Tm), y = tv(Y);
+                if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr)) return -1;
+                snprintf(name, sizeof(name), "body.%d.body.%d.body.2", g, b);
+                const int mb = pick_rows_per_wave(m, h, w, nf, 64, ns);
+                if (ex->conv(name, t, h, w, SRMI_ACT_NONE, false, 1.f, nullptr, 1.f, nullptr, &y, nullptr, chansum, mb)) return -1;
+                const CaW& ca = m->cas[ca_index++];
+                if (srmi_ca_scale(chansum, ns, srmi_conv3x3_tiles(h, w, mb), nf, cr, h * w, ca.w1, ca.b1, ca.w2, ca.b2, scale, ex->stream)) return -1;
+                // x + res_scale * (y * s)   (rcan_model.py:94-97)
+                srmi_tensor_t xres;
+                if (!split) xres = tv(XT[k]);
+                else xres = trunk_in_xr ? tv(XR[kr]) : tv(Gin);
+                const srmi_tensor_t o1 = tv(XT[k ^ 1]);
+                srmi_tensor_t o2b = split ? tv(XR[kr ^ 1]) : srmi_tensor_t{};
+                if (srmi_ca_apply(&y, &xres, scale, d.res_scale, ns, h, w, nf, &o1, split ? &o2b : nullptr, ex->stream)) return -1;
+                k ^= 1;
+                if (split) { kr ^= 1; trunk_in_xr = true; }
+            }
+            // group tail conv + group input (rcan_model.py:109-112); its output is the next group's input
+            snprintf(name, sizeof(name), "body.%d.body.%d", g, d.n_blocks);
+            const srmi_tensor_t in = tv(XT[k]), res = tv(Gin), o1 = tv(XT[k ^ 1]), og = tv(GI[(g + 1) & 1]);
+            if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, &og)) return -1;
+            k ^= 1;
+            trunk_in_xr = false;  // the trunk in trunk dtype is now GI[(g+1)&1]
+        }
+        snprintf(name, sizeof(name), "body.%d", d.n_groups);
+        const srmi_tensor_t in = tv(XT[k]), res = tv(H), o1 = tv(XT[k ^ 1]);
+        if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, nullptr)) return -1;
+        return run_tail_stages(m, A, ex, io, XT[k ^ 1], h, w);
+    }
+    return run_tail_stages(m, A, nullptr, io, XT[0], h, w);
+}
+
+static int run_plan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, int w) {
+    switch (m->d.arch) {
+        case SRMI_ARCH_RRDBNET: return run_rrdbnet(m, A, ex, io, h, w);
+        case SRMI_ARCH_EDSR: return run_edsr(m, A, ex, io, h, w);
+        case SRMI_ARCH_RCAN: return run_rcan(m, A, ex, io, h, w);
+    }
+    SRMI_FAIL("unknown architecture %d", m->d.arch);
+}
+
+static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t stream) {
+    if (!m) SRMI_FAIL("forward: null model");
+    if (!m->finalized) SRMI_FAIL("forward: srmi_model_finalize has not been called");
+    if (!io.in || !io.out) SRMI_FAIL("forward: null input or output pointer");
+    if (n <= 0 || h <= 0 || w <= 0) SRMI_FAIL("forward: bad shape n=%d h=%d w=%d", n, h, w);
+    SRMI_HIP(hipSetDevice(m->d.device));
+    const int ns = n < m->sweep ? n : m->sweep;
+    Arena probe;
+    probe.ns = ns;
+    if (run_plan(m, probe, nullptr, &io, h, w)) return -1;
+    if (probe.off > m->ws_bytes) {
+        // growing the workspace is the only allocation on the forward path; wait for work that
+        // may still use the old buffer first
+        SRMI_HIP(hipDeviceSynchronize());
+        if (m->ws) SRMI_HIP(hipFree(m->ws));
+        m->ws = nullptr;
+        m->ws_bytes = 0;
+        SRMI_HIP(hipMalloc((void**)&m->ws, probe.off));
+        m->ws_bytes = probe.off;
+    }
+    const size_t in_img = io.in_kind == SRMI_IN_U8_NHWC ? (size_t)h * w * 3 : (size_t)h * w * 3 * sizeof(float);
+    const size_t hh = (size_t)h * m->d.scale, ww = (size_t)w * m->d.scale;
+    const size_t out_img = io.tail_mode == SRMI_TAIL_U8_NHWC ? hh * ww * 3 : hh * ww * 3 * sizeof(float);
+    const char* in0 = (const char*)io.in;
+    char* out0 = (char*)io.out;
+    for (int i = 0; i < n; i += ns) {
+        Exec ex;
+        ex.m = m;
+        ex.stream = stream;
+        ex.ns = (n - i) < ns ? (n - i) : ns;
+        Arena A;
+        A.base = m->ws;
+        A.ns = ns;
+        io.in = in0 + (size_t)i * in_img;
+        io.out = out0 + (size_t)i * out_img;
+        if (run_plan(m, A, &ex, &io, h, w)) return -1;
+    }
+    return 0;
+}
+
+}  // namespace srmi
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" int srmi_model_create(const srmi_model_desc_t* desc, srmi_model_t** out) {
+    if (!desc || !out) SRMI_FAIL("srmi_model_create: null argument");
+    const srmi_model_desc_t& d = *desc;
+    if (d.dtype != SRMI_F32 && d.dtype != SRMI_F16 && d.dtype != SRMI_BF16) SRMI_FAIL("srmi_model_create: bad dtype %d", d.dtype);
+    if (d.n_feats <= 0 || d.n_feats % 32) SRMI_FAIL("srmi_model_create: n_feats=%d must be a positive multiple of 32", d.n_feats);
+    if (d.n_blocks <= 0) SRMI_FAIL("srmi_model_create: n_blocks=%d", d.n_blocks);
+    if (d.arch == SRMI_ARCH_RRDBNET) {
+        // realesrgan_model.py:82-88
+        if (d.scale != 2 && d.scale != 4) SRMI_FAIL("Unsupported scale: %d. Supported scales: 2, 4", d.scale);
+        if (d.grow_ch <= 0 || d.grow_ch % 32) SRMI_FAIL("srmi_model_create: num_grow_ch=%d must be a positive multiple of 32", d.grow_ch);
+    } else if (d.arch == SRMI_ARCH_EDSR || d.arch == SRMI_ARCH_RCAN) {
+        // edsr_model.py:54-75: powers of two, or 3
+        const bool pow2 = d.scale >= 2 && (d.scale & (d.scale - 1)) == 0;
+        if (!pow2 && d.scale != 3) SRMI_FAIL("scale %d is not supported", d.scale);
+        if (d.arch == SRMI_ARCH_RCAN) {
+            if (d.n_groups <= 0) SRMI_FAIL("srmi_model_create: n_resgroups=%d", d.n_groups);
+            if (d.reduction <= 0 || d.n_feats % d.reduction) SRMI_FAIL("srmi_model_create: reduction=%d does not divide n_feats", d.reduction);
+        }
+    } else {
+        SRMI_FAIL("srmi_model_create: unknown architecture %d", d.arch);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        SRMI_FAIL("srmi_model_create: no HIP device available (this library has no CPU path)");
+    }
+    if (d.device < 0 || d.device >= ndev) SRMI_FAIL("srmi_model_create: device %d out of range (%d devices)", d.device, ndev);
+    srmi_model* m = new srmi_model();
+    m->d = d;
+    if (m->d.dtype == SRMI_F32) m->d.trunk_f32 = 0;
+    for (int i = 0; i < 9; ++i) m->sub_mat[i] = m->add_mat[i] = kIdentity[i];
+    for (int i = 0; i < 3; ++i) m->sub_bias[i] = m->add_bias[i] = 0.f;
+    const char* e = getenv("SRMI_ROWS_PER_WAVE");
+    if (e && atoi(e) >= 2 && atoi(e) <= 4) m->mb_override = atoi(e);
+    build_keys(m);
+    *out = m;
+    return 0;
+}
+
+extern "C" void srmi_model_destroy(srmi_model_t* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->d.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : m->dev_allocs) (void)hipFree(p);
+    if (m->ws) (void)hipFree(m->ws);
+    delete m;
+}
+
+extern "C" int srmi_model_num_keys(const srmi_model_t* m) { return m ? (int)m->keys.size() : 0; }
+
+extern "C" const char* srmi_model_key(const srmi_model_t* m, int i) {
+    if (!m || i < 0 || i >= (int)m->keys.size()) return nullptr;
+    return m->keys[i].c_str();
+}
+
+extern "C" int srmi_model_set_tensor(srmi_model_t* m, const char* key, const float* data,
+                                     const int64_t* shape, int ndim) {
+    if (!m || !key || !data || !shape) SRMI_FAIL("srmi_model_set_tensor: null argument");
+    auto it = m->tensors.find(key);
+    if (it == m->tensors.end()) SRMI_FAIL("unexpected key \"%s\" in state_dict", key);
+    HostTensor& t = it->second;
+    std::vector<int64_t> s(shape, shape + ndim);
+    if (s != t.shape) {
+        std::string got, want;
+        for (auto v : s) got += std::to_string(v) + ",";
+        for (auto v : t.shape) want += std::to_string(v) + ",";
+        SRMI_FAIL("size mismatch for %s: checkpoint shape (%s) vs model shape (%s)", key, got.c_str(), want.c_str());
+    }
+    t.data.assign(data, data + numel(s));
+    t.set = true;
+    m->finalized = false;
+    return 0;
+}
+
+extern "C" int srmi_model_finalize(srmi_model_t* m) {
+    if (!m) SRMI_FAIL("srmi_model_finalize: null model");
+    for (const auto& k : m->keys)
+        if (!m->tensors[k].set) SRMI_FAIL("missing key \"%s\" in state_dict", k.c_str());
+    SRMI_HIP(hipSetDevice(m->d.device));
+    SRMI_HIP(hipDeviceSynchronize());
+    for (void* p : m->dev_allocs) (void)hipFree(p);
+    m->dev_allocs.clear();
+    m->convs.clear();
+    m->cas.clear();
+    const auto& d = m->d;
+    if (d.arch == SRMI_ARCH_RRDBNET) {
+        if (upload_first(m, "conv_first")) return -1;
+        for (const auto& k : m->keys) {
+            if (k.size() < 7 || k.compare(k.size() - 7, 7, ".weight")) continue;
+            const std::string name = k.substr(0, k.size() - 7);
+            if (name == "conv_first") continue;
+            if (upload_conv(m, name, 1)) return -1;
+        }
+    } else {
+        if (d.with_meanshift) {
+            // MeanShift is a 1x1 conv stored in the checkpoint: general 3x3 matrix + bias
+            memcpy(m->sub_mat, m->tensors["sub_mean.weight"].data.data(), 9 * sizeof(float));
+            memcpy(m->sub_bias, m->tensors["sub_mean.bias"].data.data(), 3 * sizeof(float));
+            memcpy(m->add_mat, m->tensors["add_mean.weight"].data.data(), 9 * sizeof(float));
+            memcpy(m->add_bias, m->tensors["add_mean.bias"].data.data(), 3 * sizeof(float));
+        }
+        if (upload_first(m, "head.0")) return -1;
+        int r;
+        upsampler_stages(d.scale, &r);
+        for (const auto& k : m->keys) {
+            if (k.size() < 7 || k.compare(k.size() - 7, 7, ".weight")) continue;
+            const std::string name = k.substr(0, k.size() - 7);
+            if (name == "head.0" || name == "sub_mean" || name == "add_mean") continue;
+            if (name.find("conv_du") != std::string::npos) continue;
+            const bool is_up = name.compare(0, 7, "tail.0.") == 0;
+            if (upload_conv(m, name, is_up ? r : 1)) return -1;
+        }
+        if (d.arch == SRMI_ARCH_RCAN) {
+            char name[128];
+            for (int g = 0; g < d.n_groups; ++g)
+                for (int b = 0; b < d.n_blocks; ++b) {
+                    CaW ca;
+                    snprintf(name, sizeof(name), "body.%d.body.%d.body.3.conv_du.", g, b);
+                    const std::string p = name;
+                    const HostTensor& w1 = m->tensors[p + "0.weight"];
+                    const HostTensor& b1 = m->tensors[p + "0.bias"];
+                    const HostTensor& w2 = m->tensors[p + "2.weight"];
+                    const HostTensor& b2 = m->tensors[p + "2.bias"];
+                    if (dev_upload(m, w1.data.data(), w1.data.size() * 4, (void**)&ca.w1)) return -1;
+                    if (dev_upload(m, b1.data.data(), b1.data.size() * 4, (void**)&ca.b1)) return -1;
+                    if (dev_upload(m, w2.data.data(), w2.data.size() * 4, (void**)&ca.w2)) return -1;
+                    if (dev_upload(m, b2.data.data(), b2.data.size() * 4, (void**)&ca.b2)) return -1;
+                    m->cas.push_back(ca);
+                }
+        }
+    }
+    m->finalized = true;
+    return 0;
+}
+
+extern "C" int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* out, int n, int h, int w,
+                                      void* hip_stream) {
+    if (!m) SRMI_FAIL("srmi_model_forward_f32: null model");
+    IoSpec io;
+    memset(&io, 0, sizeof(io));
+    io.in_kind = SRMI_IN_F32_NCHW;
+    io.in = in;
+    io.tail_mode = SRMI_TAIL_F32_NCHW;
+    io.out = out;
+    const bool ms = m->d.arch != SRMI_ARCH_RRDBNET && m->d.with_meanshift;
+    memcpy(io.pre_mat, ms ? m->sub_mat : kIdentity, sizeof(io.pre_mat));
+    memcpy(io.post_mat, ms ? m->add_mat : kIdentity, sizeof(io.post_mat));
+    for (int i = 0; i < 3; ++i) {
+        io.pre_bias[i] = ms ? m->sub_bias[i] : 0.f;
+        io.post_bias[i] = ms ? m->add_bias[i] : 0.f;
+    }
+    return forward(m, io, n, h, w, (hipStream_t)hip_stream);
+}
+
+extern "C" int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
+                                     int round_mode, void* hip_stream) {
+    if (!m) SRMI_FAIL("srmi_model_forward_u8: null model");
+    if (round_mode < 0 || round_mode > 2) SRMI_FAIL("srmi_model_forward_u8: bad round_mode %d", round_mode);
+    IoSpec io;
+    memset(&io, 0, sizeof(io));
+    io.in_kind = SRMI_IN_U8_NHWC;
+    io.in = in;
+    io.tail_mode = SRMI_TAIL_U8_NHWC;
+    io.out = out;
+    io.round = round_mode;
+    memcpy(io.pre_mat, kIdentity, sizeof(io.pre_mat));
+    memcpy(io.post_mat, kIdentity, sizeof(io.post_mat));
+    if (m->d.arch == SRMI_ARCH_RRDBNET) {
+        // realesrgan.cpp:35,44 (p * (1/255)) and :124-126 (clamp(v,0,1)*255)
+        const float s = 1.0f / 255.0f;
+        io.pre_mat[0] = io.pre_mat[4] = io.pre_mat[8] = s;
+        io.lo = 0.f; io.hi = 1.f; io.scale = 255.f;
+    } else {
+        // edsr.cpp:36-37 (p - mean*range), :116-118 (clamp(v + mean*range, 0, 255)).  With a full
+        // model the shift comes from the checkpoint's MeanShift tensors, with a core model the
+        // caller's tensors are used as they are (identity, no shift).
+        if (m->d.with_meanshift) {
+            memcpy(io.pre_mat, m->sub_mat, sizeof(io.pre_mat));
+            memcpy(io.post_mat, m->add_mat, sizeof(io.post_mat));
+            for (int i = 0; i < 3; ++i) { io.pre_bias[i] = m->sub_bias[i]; io.post_bias[i] = m->add_bias[i]; }
+        }
+        io.lo = 0.f; io.hi = 255.f; io.scale = 1.f;
+    }
+    return forward(m, io, n, h, w, (hipStream_t)hip_stream);
+}
+
+extern "C" size_t srmi_model_workspace_bytes(const srmi_model_t* m) { return m ? m->ws_bytes : 0; }
+
+extern "C" int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep) {
+    if (!m || images_per_sweep < 1) SRMI_FAIL("srmi_model_set_sweep: bad argument");
+    m->sweep = images_per_sweep;
+    return 0;
+}
+
+extern "C" double srmi_model_flops(const srmi_model_t* m, int h, int w) {
+    if (!m) return 0.0;
+    const auto& d = m->d;
+    const double px = (double)h * w, nf = d.n_feats;
+    auto cv = [](double cin, double cout, double pixels) { return 2.0 * cin * cout * 9.0 * pixels; };
+    double f = cv(3, nf, px);
+    if (d.arch == SRMI_ARCH_RRDBNET) {
+        const double gc = d.grow_ch;
+        double rdb = 0;
+        for (int j = 0; j < 4; ++j) rdb += cv(nf + j * gc, gc, px);
+        rdb += cv(nf + 4 * gc, nf, px);
+        f += 3.0 * d.n_blocks * rdb + cv(nf, nf, px);
+        f += cv(nf, nf, 4 * px);
+        double hr = 4 * px;
+        if (d.scale == 4) { f += cv(nf, nf, 16 * px); hr = 16 * px; }
+        f += cv(nf, nf, hr) + cv(nf, 3, hr);
+        return f;
+    }
+    if (d.arch == SRMI_ARCH_EDSR) f += (2.0 * d.n_blocks + 1) * cv(nf, nf, px);
+    else f += (d.n_groups * (2.0 * d.n_blocks + 1) + 1) * cv(nf, nf, px);
+    int r;
+    const int stages = upsampler_stages(d.scale, &r);
+    double p = px;
+    for (int s = 0; s < stages; ++s) { f += cv(nf, r * r * nf, p); p *= r * r; }
+    f += cv(nf, 3, p);
+    return f;
+}

@@ -1,0 +1,114 @@
+// Host-side repacking of OIHW float32 convolution weights into the LDS image the conv kernel
+// stages with LDS-DMA.
+//
+// Packed layout: [cout tile][cin block][tap = ky*3+kx][row = output channel within tile][64 bytes]
+// where the 64 bytes are the block's input channels (32 halves or 16 floats) as four 16-byte
+// chunks, stored chunk index = logical chunk ^ ((row_in_image >> 2) & 3), row_in_image =
+// tap * cout_tile + row.  With pixel-shuffle packing the output channels are permuted so that a
+// 32-channel block holds one (i, j) sub-pixel position of 32 consecutive post-shuffle channels.
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace srmi {
+
+static inline uint16_t f32_to_f16(float f) {
+    // round-to-nearest-even, IEEE binary16 with subnormals
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((x > 0x7F800000u) ? 0x200u : 0u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);  // rounds to inf
+    if (x < 0x33000001u) return (uint16_t)sign;               // rounds to zero
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) {  // subnormal half
+        shift = 13 + (-14 - e);
+        base = 0;
+    } else {
+        shift = 13;
+        base = (uint32_t)(e + 15) << 10;
+        m &= 0x7FFFFFu;
+    }
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u);
+    const uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    return (uint16_t)(sign | (base + q));
+}
+
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    if ((x & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((x >> 16) | 0x40u);  // NaN stays NaN
+    x += 0x7FFFu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+
+// packed output channel -> original output channel (or -1 for padding)
+static inline int packed_to_orig(int q, int cout, int r) {
+    if (q >= cout) return -1;
+    if (r <= 1) return q;
+    const int c_after = cout / (r * r);
+    const int ij = q / c_after, c = q - ij * c_after;
+    return c * r * r + ij;
+}
+
+}  // namespace srmi
+
+using namespace srmi;
+
+extern "C" size_t srmi_pack_conv3x3_bytes(int dtype, int cout, int cin, int cout_tile,
+                                          int* bias_floats) {
+    if (cout_tile != 32 && cout_tile != 64) return 0;
+    const int cpb = dtype_cpb(dtype);
+    if (cin <= 0 || cin % cpb || cout <= 0) return 0;
+    const int ntile = (cout + cout_tile - 1) / cout_tile;
+    if (bias_floats) *bias_floats = ntile * cout_tile;
+    return (size_t)ntile * (cin / cpb) * 9 * cout_tile * 64;
+}
+
+extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, int ps_r,
+                                 const float* w, const float* bias, void* wpk_out,
+                                 float* bias_out) {
+    int nbias = 0;
+    const size_t bytes = srmi_pack_conv3x3_bytes(dtype, cout, cin, cout_tile, &nbias);
+    if (!bytes) SRMI_FAIL("srmi_pack_conv3x3: bad shape dtype=%d cout=%d cin=%d cout_tile=%d", dtype, cout, cin, cout_tile);
+    if (!w || !wpk_out || !bias_out) SRMI_FAIL("srmi_pack_conv3x3: null pointer");
+    const int r = ps_r <= 1 ? 1 : ps_r;
+    if (r > 1 && cout % (r * r * 32)) SRMI_FAIL("srmi_pack_conv3x3: cout=%d incompatible with pixel shuffle %d", cout, r);
+    const int cpb = dtype_cpb(dtype), esz = dtype_size(dtype), epc = 16 / esz;  // elements per chunk
+    const int ncb = cin / cpb, ntile = nbias / cout_tile;
+    char* out = (char*)wpk_out;
+    for (int t = 0; t < ntile; ++t)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int row = 0; row < cout_tile; ++row) {
+                    const int o = packed_to_orig(t * cout_tile + row, cout, r);
+                    const int img_row = tap * cout_tile + row;
+                    char* dst_row = out + ((((size_t)t * ncb + cb) * 9 + tap) * cout_tile + row) * 64;
+                    for (int c = 0; c < 4; ++c) {
+                        char* dst = dst_row + ((c ^ ((img_row >> 2) & 3)) << 4);
+                        for (int e = 0; e < epc; ++e) {
+                            const int ci = cb * cpb + c * epc + e;
+                            const float v = o < 0 ? 0.f : w[((size_t)o * cin + ci) * 9 + tap];
+                            if (dtype == SRMI_F32) {
+                                memcpy(dst + 4 * e, &v, 4);
+                            } else {
+                                const uint16_t hv = dtype == SRMI_F16 ? f32_to_f16(v) : f32_to_bf16(v);
+                                memcpy(dst + 2 * e, &hv, 2);
+                            }
+                        }
+                    }
+                }
+    for (int q = 0; q < nbias; ++q) {
+        const int o = packed_to_orig(q, cout, r);
+        bias_out[q] = (o < 0 || !bias) ? 0.f : bias[o];
+    }
+    return 0;
+}

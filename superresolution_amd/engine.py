@@ -1,0 +1,169 @@
+"""Model-level Python surface: `Engine` wraps the C executor (srmi_model_* in include/srmi355.h),
+`HipModule` is the nn.Module base the three network classes derive from.
+
+A forward pass is ONE ctypes call; all layer sequencing, workspace management and kernel
+launches happen inside libsrmi355.so on the caller's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, lib
+
+
+def resolve_dtype(name):
+    """'f32' | 'f16' | 'bf16' (or None -> $SRMI_DTYPE, default f16) -> library dtype code."""
+    if name is None:
+        name = os.environ.get("SRMI_DTYPE", "f16")
+    if isinstance(name, torch.dtype):
+        name = {torch.float32: "f32", torch.float16: "f16", torch.bfloat16: "bf16"}[name]
+    if isinstance(name, str):
+        try:
+            return _lib.DTYPE_NAMES[name.lower()]
+        except KeyError:
+            raise ValueError(f"unknown compute dtype {name!r}") from None
+    return int(name)
+
+
+class Engine:
+    """Owns one `srmi_model_t`."""
+
+    def __init__(self, arch, *, dtype, scale, n_feats, n_blocks, n_groups=0, grow_ch=0, reduction=0,
+                 res_scale=1.0, with_meanshift=False, trunk_f32=True, device=0):
+        d = _lib.ModelDesc()
+        d.arch, d.dtype, d.scale = arch, dtype, scale
+        d.n_feats, d.n_blocks, d.n_groups = n_feats, n_blocks, n_groups
+        d.grow_ch, d.reduction, d.res_scale = grow_ch, reduction, res_scale
+        d.with_meanshift, d.trunk_f32, d.device = int(with_meanshift), int(trunk_f32), device
+        self.desc = d
+        self.scale = scale
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        check(lib().srmi_model_create(C.byref(d), C.byref(h)), "srmi_model_create")
+        self._h = h
+        self._finalized = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().srmi_model_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def keys(self):
+        n = lib().srmi_model_num_keys(self._h)
+        return [lib().srmi_model_key(self._h, i).decode() for i in range(n)]
+
+    def load_state_dict(self, sd):
+        """sd: mapping key -> float tensor / ndarray in the reference's layout (strict)."""
+        for k, v in sd.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(lib().srmi_model_set_tensor(self._h, k.encode(), a.ctypes.data, shape, a.ndim),
+                  "srmi_model_set_tensor")
+        check(lib().srmi_model_finalize(self._h), "srmi_model_finalize")
+        self._finalized = True
+
+    def set_sweep(self, images_per_sweep):
+        check(lib().srmi_model_set_sweep(self._h, int(images_per_sweep)), "srmi_model_set_sweep")
+
+    def workspace_bytes(self):
+        return int(lib().srmi_model_workspace_bytes(self._h))
+
+    def flops(self, h, w):
+        return float(lib().srmi_model_flops(self._h, h, w))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def forward_f32(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """x: float32 NCHW on this engine's GPU -> float32 NCHW [n,3,h*scale,w*scale]."""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected [N,3,H,W], got {tuple(x.shape)}")
+        x = x.to(self.device, torch.float32).contiguous()
+        n, _, h, w = x.shape
+        if out is None:
+            out = torch.empty((n, 3, h * self.scale, w * self.scale), dtype=torch.float32, device=self.device)
+        check(lib().srmi_model_forward_f32(self._h, x.data_ptr(), out.data_ptr(), n, h, w, self._stream()),
+              "srmi_model_forward_f32")
+        return out
+
+    def forward_u8(self, img: torch.Tensor, round_mode=_lib.ROUND_HALF_UP, out: torch.Tensor = None) -> torch.Tensor:
+        """img: uint8 NHWC (or HWC) on this engine's GPU -> uint8 NHWC, runner pre/post fused."""
+        squeeze = img.dim() == 3
+        if squeeze:
+            img = img.unsqueeze(0)
+        if img.dim() != 4 or img.shape[3] != 3 or img.dtype != torch.uint8:
+            raise ValueError(f"expected uint8 [N,H,W,3], got {img.dtype} {tuple(img.shape)}")
+        img = img.to(self.device).contiguous()
+        n, h, w, _ = img.shape
+        if out is None:
+            out = torch.empty((n, h * self.scale, w * self.scale, 3), dtype=torch.uint8, device=self.device)
+        check(lib().srmi_model_forward_u8(self._h, img.data_ptr(), out.data_ptr(), n, h, w, round_mode,
+                                          self._stream()), "srmi_model_forward_u8")
+        return out[0] if squeeze else out
+
+
+class HipModule(nn.Module):
+    """nn.Module whose parameters live in the reference's module tree (so the official
+    checkpoints load with the reference's own key names) and whose forward runs on the GPU
+    through an `Engine`.  Parameters are re-uploaded automatically when they change."""
+
+    def __init__(self, compute_dtype=None, trunk_f32=True, device=None):
+        super().__init__()
+        self._srmi_dtype = resolve_dtype(compute_dtype)
+        self._srmi_trunk_f32 = bool(trunk_f32)
+        self._srmi_device = device
+        self._srmi_engine = None
+        self._srmi_stamp = None
+
+    # subclasses return the Engine constructor kwargs
+    def _engine_config(self):
+        raise NotImplementedError
+
+    def _param_stamp(self):
+        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+
+    def engine(self) -> Engine:
+        """The up-to-date executor (uploads the weights on first use and after any change)."""
+        stamp = self._param_stamp()
+        if self._srmi_engine is None or stamp != self._srmi_stamp:
+            dev = self._srmi_device
+            if dev is None:
+                first = next(iter(self.parameters()))
+                dev = first.device.index if first.is_cuda else 0
+            if self._srmi_engine is None:
+                self._srmi_engine = Engine(dtype=self._srmi_dtype, trunk_f32=self._srmi_trunk_f32, device=dev or 0,
+                                           **self._engine_config())
+            sd = self.state_dict()
+            want = self._srmi_engine.keys()
+            self._srmi_engine.load_state_dict({k: sd[k] for k in want})
+            self._srmi_stamp = stamp
+        return self._srmi_engine
+
+    def forward(self, x):
+        """f32 NCHW in -> f32 NCHW out, the reference modules' forward contract.  The result is
+        returned on the input's device."""
+        eng = self.engine()
+        y = eng.forward_f32(x)
+        return y if x.is_cuda else y.to(x.device)
+
+    def forward_u8(self, img, round_mode=_lib.ROUND_HALF_UP):
+        """u8 HWC/NHWC in -> u8 out with the runners' pre/post-processing fused."""
+        eng = self.engine()
+        t = torch.as_tensor(img)
+        y = eng.forward_u8(t, round_mode)
+        return y if t.is_cuda else y.cpu()
+
+
+def conv_params(cin, cout, k):
+    """A parameter container with nn.Conv2d's names, shapes and default initialisation."""
+    return nn.Conv2d(cin, cout, k, padding=k // 2, bias=True)

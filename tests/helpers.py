@@ -1,0 +1,72 @@
+"""Shared helpers of the test-suite: fixture loading, state_dict / input regeneration, oracle
+dispatch."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from oracle import sr_oracle as O
+from superresolution_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "ops.npz")
+
+
+def load_case(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    return ast.literal_eval(str(z["meta"])), z["y"]
+
+
+def state_dict_for(meta):
+    a = meta["arch"]
+    if a == "rrdbnet":
+        return synth.rrdbnet_state_dict(num_block=meta["num_block"], scale=meta["scale"], seed=meta["seed"])
+    if a == "edsr":
+        return synth.edsr_state_dict(n_resblocks=meta["n_resblocks"], n_feats=meta["n_feats"], scale=meta["scale"],
+                                     seed=meta["seed"])
+    return synth.rcan_state_dict(scale=meta["scale"], n_resgroups=meta["n_resgroups"], n_resblocks=meta["n_resblocks"],
+                                 seed=meta["seed"])
+
+
+def input_for(meta):
+    img = synth.random_image(meta["h"], meta["w"], meta["seed"], n=meta["n"]).astype(np.float32)
+    if meta["input"] == "unit":
+        img = img * np.float32(1.0 / 255.0)
+    return torch.from_numpy(img).permute(0, 3, 1, 2).contiguous()
+
+
+def oracle_forward(meta, sd, x):
+    a = meta["arch"]
+    with torch.no_grad():
+        if a == "rrdbnet":
+            return O.rrdbnet_forward(sd, x, num_block=meta["num_block"], scale=meta["scale"])
+        if a == "edsr":
+            return O.edsr_forward(sd, x, n_resblocks=meta["n_resblocks"], scale=meta["scale"], res_scale=0.1)
+        return O.rcan_forward(sd, x, scale=meta["scale"], n_resgroups=meta["n_resgroups"],
+                              n_resblocks=meta["n_resblocks"], res_scale=1.0)
+
+
+def build_model(meta, compute_dtype, trunk_f32=True):
+    """The product module (superresolution_amd) for a fixture's architecture, weights loaded."""
+    from superresolution_amd import EDSR, RCAN, RRDBNet
+    a = meta["arch"]
+    kw = dict(compute_dtype=compute_dtype, trunk_f32=trunk_f32)
+    if a == "rrdbnet":
+        m = RRDBNet(num_block=meta["num_block"], scale=meta["scale"], **kw)
+    elif a == "edsr":
+        m = EDSR(n_resblocks=meta["n_resblocks"], n_feats=meta["n_feats"], scale=meta["scale"], **kw)
+    else:
+        m = RCAN(scale=meta["scale"], n_resgroups=meta["n_resgroups"], n_resblocks=meta["n_resblocks"], **kw)
+    sd = state_dict_for(meta)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m, sd
+
+
+# fp32 parity bound of the task statement: max-abs <= 1e-4 on the [0,1] image scale; EDSR / RCAN
+# work in the 0..255 domain (rgb_range = 255), so the same bound reads 1e-4 * 255 there.
+def f32_tol(meta):
+    return 1e-4 if meta["input"] == "unit" else 1e-4 * 255.0

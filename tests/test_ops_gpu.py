@@ -1,0 +1,232 @@
+"""Operator-level parity on the GPU: every HIP kernel, called through the C ABI, against the CPU
+oracle (torch fp32 functional ops, the arithmetic the reference modules use).
+
+Tolerances: f32 kernels 2e-5 relative to the output scale (summation order only differs);
+f16/bf16 kernels are fed operands already rounded to the half type, so the remaining difference is
+fp32 accumulation order plus ONE output rounding: 2^-10 (f16) / 2^-7 (bf16) relative.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sr_oracle as O
+from superresolution_amd import _lib, ops, synth
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [(_lib.F32, "f32", 2e-5), (_lib.F16, "f16", 2.0 ** -10), (_lib.BF16, "bf16", 2.0 ** -7)]
+TORCH_DT = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}
+
+
+def q(x, dt):
+    """Round a float tensor to the compute dtype and back (what the kernel's operands hold)."""
+    return x.to(TORCH_DT[dt]).to(torch.float32)
+
+
+def rnd(key, shape, seed=0, amp=1.0):
+    return torch.from_numpy(synth.hash_uniform(key, shape, seed)) * amp
+
+
+def assert_close(got, ref, rel, what=""):
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= rel * scale, f"{what}: max err {err:.3e} > {rel:.1e} * {scale:.3e}"
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+@pytest.mark.parametrize("mb", [2, 3, 4])
+def test_conv_64_64_relu(dt, name, tol, mb):
+    n, h, w = 2, 33, 47
+    x = q(rnd("x", (n, 64, h, w), 1), dt)
+    wt = q(rnd("w", (64, 64, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (64,), 3)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt)
+    out = ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, act=_lib.ACT_RELU, rows_per_wave=mb,
+                      out_dtype=_lib.F32)
+    assert_close(out.to_nchw().cpu(), ref, 2e-5 if dt == _lib.F32 else 1e-5 * 50, f"conv {name} mb={mb}")
+    # and with the output rounded to the compute dtype
+    out = ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, act=_lib.ACT_RELU, rows_per_wave=mb)
+    assert_close(out.to_nchw().cpu(), ref, tol, f"conv {name} mb={mb} (typed out)")
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_rdb_conv5_two_residuals(dt, name, tol):
+    # x5*0.2 + x, then *0.2 + R  (realesrgan_model.py:32,49); trunk copies in f32
+    n, h, w = 1, 21, 70
+    x = q(rnd("x", (n, 192, h, w), 1), dt)
+    wt = q(rnd("w", (64, 192, 3, 3), 2, 0.05), dt)
+    b = rnd("b", (64,), 3)
+    r1 = rnd("r1", (n, 64, h, w), 4)
+    r2 = rnd("r2", (n, 64, h, w), 5)
+    ref = (F.conv2d(x, wt, b, padding=1) * 0.2 + r1) * 0.2 + r2
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt)
+    out2 = ops.Planes(n, 64, h, w, _lib.F32)
+    out = ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, alpha=0.2, res1=ops.Planes.from_nchw(r1, _lib.F32),
+                      beta=0.2, res2=ops.Planes.from_nchw(r2, _lib.F32), out2=out2)
+    assert_close(out2.to_nchw().cpu(), ref, 2e-5 if dt == _lib.F32 else 5e-4, f"conv5 {name} f32 copy")
+    assert_close(out.to_nchw().cpu(), ref, tol, f"conv5 {name}")
+    # residual given in the compute dtype
+    r1q = q(r1, dt)
+    ref = F.conv2d(x, wt, b, padding=1) * 0.2 + r1q
+    out = ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, alpha=0.2, res1=ops.Planes.from_nchw(r1q, dt))
+    assert_close(out.to_nchw().cpu(), ref, tol, f"conv5 {name} typed residual")
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_dense_slice_store_lrelu(dt, name, tol):
+    # conv2 of a ResidualDenseBlock: reads channels 0..95 of the 192-channel dense buffer, writes
+    # 32 channels at offset 96 (torch.cat replaced by slice stores; realesrgan_model.py:27-28)
+    n, h, w = 1, 16, 40
+    full = q(rnd("x", (n, 192, h, w), 1), dt)
+    wt = q(rnd("w", (32, 96, 3, 3), 2, 0.05), dt)
+    b = rnd("b", (32,), 3)
+    ref = F.leaky_relu(F.conv2d(full[:, :96], wt, b, padding=1), 0.2)
+    dense = ops.Planes.from_nchw(full, dt)
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt)
+    assert pc.cout_tile == 32
+    ops.conv3x3(dense, pc, act=_lib.ACT_LRELU, out=dense, out_c0=96)
+    got = dense.to_nchw().cpu()
+    assert_close(got[:, 96:128], ref, tol, f"slice {name}")
+    assert torch.equal(got[:, :96], full[:, :96]) and torch.equal(got[:, 128:], full[:, 128:])
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_nearest_up2_loader(dt, name, tol):
+    n, h, w = 1, 13, 19
+    x = q(rnd("x", (n, 64, h, w), 1), dt)
+    wt = q(rnd("w", (64, 64, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (64,), 3)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1), 0.2)
+    out = ops.conv3x3(ops.Planes.from_nchw(x, dt), ops.PackedConv(wt.numpy(), b.numpy(), dt),
+                      act=_lib.ACT_LRELU, up2=True)
+    assert (out.h, out.w) == (2 * h, 2 * w)
+    assert_close(out.to_nchw().cpu(), ref, tol, f"up2 {name}")
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+@pytest.mark.parametrize("r", [2, 3])
+def test_pixel_shuffle_store(dt, name, tol, r):
+    n, h, w = 1, 11, 37
+    x = q(rnd("x", (n, 64, h, w), 1), dt)
+    wt = q(rnd("w", (64 * r * r, 64, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (64 * r * r,), 3)
+    ref = F.pixel_shuffle(F.conv2d(x, wt, b, padding=1), r)
+    out = ops.conv3x3(ops.Planes.from_nchw(x, dt), ops.PackedConv(wt.numpy(), b.numpy(), dt, ps_r=r))
+    assert (out.c, out.h, out.w) == (64, h * r, w * r)
+    assert_close(out.to_nchw().cpu(), ref, tol, f"ps{r} {name}")
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_rgb_tail(dt, name, tol):
+    n, h, w = 2, 19, 45
+    x = q(rnd("x", (n, 64, h, w), 1), dt)
+    wt = q(rnd("w", (3, 64, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (3,), 3) + 0.5
+    core = F.conv2d(x, wt, b, padding=1)
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=32)
+    xp = ops.Planes.from_nchw(x, dt)
+    ftol = 2e-5 if dt == _lib.F32 else 5e-4
+    # f32 NCHW with a general 3x3 colour matrix (add_mean as a 1x1 conv, edsr_model.py:122)
+    mat = np.array([[1.0, 0.1, 0.0], [0.0, 0.9, 0.2], [0.3, 0.0, 1.1]], np.float32)
+    tb = np.array([0.5, -0.25, 0.125], np.float32)
+    ref = F.conv2d(core, torch.from_numpy(mat).view(3, 3, 1, 1), torch.from_numpy(tb))
+    got = ops.conv3x3(xp, pc, tail=dict(mode=_lib.TAIL_F32_NCHW, mat=mat, bias=tb))
+    assert_close(got.cpu(), ref, ftol, f"tail f32 {name}")
+    # u8 NHWC, each rounding mode (runners' post-processing)
+    for mode, omode in [(_lib.ROUND_HALF_EVEN, O.ROUND_HALF_EVEN), (_lib.ROUND_HALF_UP, O.ROUND_HALF_UP),
+                        (_lib.ROUND_TRUNC, O.ROUND_TRUNC)]:
+        got = ops.conv3x3(xp, pc, tail=dict(mode=_lib.TAIL_U8_NHWC, lo=0.0, hi=1.0, scale=255.0, round=mode))
+        ref8 = O.post_unit(core, omode)
+        diff = np.abs(got.cpu().numpy().astype(np.int32) - ref8.astype(np.int32))
+        assert diff.max() <= 1, f"tail u8 {name} mode {mode}: max diff {diff.max()}"
+        assert (diff != 0).mean() < (0.002 if dt == _lib.F32 else 0.1)
+        assert 0.02 < (ref8 == 0).mean() < 0.9  # clamping is exercised
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+@pytest.mark.parametrize("mb", [2, 4])
+def test_chansum(dt, name, tol, mb):
+    n, h, w = 2, 35, 50
+    x = q(rnd("x", (n, 64, h, w), 1), dt)
+    wt = q(rnd("w", (64, 64, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (64,), 3)
+    ref = F.conv2d(x, wt, b, padding=1)
+    out, sums = ops.conv3x3(ops.Planes.from_nchw(x, dt), ops.PackedConv(wt.numpy(), b.numpy(), dt),
+                            chansum=True, rows_per_wave=mb)
+    got = sums.sum(dim=1).cpu()
+    assert_close(got, ref.sum(dim=(2, 3)), 1e-4 if dt != _lib.F32 else 2e-5, f"chansum {name}")
+    assert_close(out.to_nchw().cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_conv_first(dt, name, tol):
+    n, h, w = 2, 17, 29
+    img = synth.random_image(h, w, 3, n=n)
+    wt = rnd("w", (64, 3, 3, 3), 2, 0.3)
+    b = rnd("b", (64,), 3)
+    # u8 path with the runners' /255 (realesrgan.cpp:28-48)
+    ref = F.conv2d(O.pre_unit(img), wt, b, padding=1)
+    out, out2 = ops.conv_first(torch.from_numpy(img).cuda(), wt.numpy(), b.numpy(), dt,
+                               pre_mat=np.eye(3, dtype=np.float32) * np.float32(1.0 / 255.0), out2_dtype=_lib.F32)
+    assert_close(out2.to_nchw().cpu(), ref, 2e-6, f"first u8 {name} f32 copy")
+    assert_close(out.to_nchw().cpu(), ref, tol, f"first u8 {name}")
+    # f32 NCHW path with MeanShift: padding must stay zero in the shifted domain (edsr_model.py:115)
+    xin = O.pre_raw(img)
+    mb_ = -255.0 * np.asarray(synth.RGB_MEAN, np.float32)
+    ref = F.conv2d(xin + torch.from_numpy(mb_).view(1, 3, 1, 1), wt, b, padding=1)
+    out = ops.conv_first(xin.cuda(), wt.numpy(), b.numpy(), _lib.F32, pre_bias=mb_)
+    assert_close(out.to_nchw().cpu(), ref, 2e-6, "first f32 meanshift")
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_channel_attention(dt, name, tol, golden_dir):
+    # CALayer + RCAB residual against the reference modules' own outputs (tests/golden/ops.npz)
+    g = np.load(f"{golden_dir}/ops.npz")
+    sd = synth.rcan_state_dict(n_resgroups=1, n_resblocks=1, seed=22)
+    p = "body.0.body.0.body.3.conv_du"
+    x = torch.from_numpy(synth.hash_uniform("rcab_in", (2, 64, 11, 15), 22)) * 50.0
+    xq = q(x, dt)
+    xp = ops.Planes.from_nchw(xq, dt)
+    sums = ops.channel_sums(xp)
+    assert_close(sums.cpu(), xq.sum(dim=(2, 3)), 1e-5, "channel_sums")
+    scale = ops.ca_scale(sums.view(2, 1, 64), 11 * 15, sd[p + ".0.weight"], sd[p + ".0.bias"],
+                         sd[p + ".2.weight"], sd[p + ".2.bias"])
+    zero = ops.Planes(2, 64, 11, 15, _lib.F32, zero=True)
+    out = ops.ca_apply(xp, zero, scale, 1.0, out_dtype=_lib.F32)
+    assert_close(out.to_nchw().cpu(), torch.from_numpy(g["ca_out"]), 2e-5 if dt == _lib.F32 else tol * 2, f"CALayer {name}")
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_permutes(dt, name, tol, golden_dir):
+    g = np.load(f"{golden_dir}/ops.npz")
+    x = torch.from_numpy(synth.hash_uniform("ps_in", (1, 36, 5, 7), 23))
+    # pad channels so that the shuffled tensor has whole 16-byte chunks: use 8x the channels
+    xx = q(torch.cat([x] * 8, dim=1), dt)  # 288 channels -> 72 (r=2) / 32 (r=3)
+    for r in (2, 3):
+        ref = F.pixel_shuffle(xx, r)
+        got = ops.pixel_shuffle(ops.Planes.from_nchw(xx, dt), r).to_nchw().cpu()
+        assert torch.equal(got, ref), f"pixel_shuffle r={r} {name}"
+    assert np.array_equal(F.pixel_shuffle(x, 2).numpy(), g["ps2_out"])
+    x64 = q(rnd("near", (2, 64, 9, 14), 5), dt)
+    got = ops.nearest_up2(ops.Planes.from_nchw(x64, dt)).to_nchw().cpu()
+    assert torch.equal(got, O.nearest_up2(x64))
+    assert np.array_equal(O.nearest_up2(x).numpy(), g["near_out"])
+
+
+def test_resize_bilinear_u8():
+    for (ih, iw, oh, ow) in [(37, 53, 339, 510), (400, 600, 256, 256), (256, 256, 256, 256), (5, 7, 3, 2)]:
+        img = synth.random_image(ih, iw, 7)
+        ref = O.resize_bilinear_u8(img, ow, oh)
+        got = ops.resize_bilinear_u8(torch.from_numpy(img).cuda(), ow, oh).cpu().numpy()
+        assert np.array_equal(got, ref), f"resize {iw}x{ih}->{ow}x{oh}: {np.abs(got.astype(int) - ref).max()}"
+
+
+def test_bad_arguments_fail_loudly():
+    pc = ops.PackedConv(np.zeros((64, 64, 3, 3), np.float32), None, _lib.F16)
+    x = ops.Planes(1, 64, 8, 8, _lib.F32)  # wrong dtype for an f16 conv
+    with pytest.raises(_lib.SrmiError):
+        ops.conv3x3(x, pc)
+    with pytest.raises(_lib.SrmiError):
+        ops.PackedConv(np.zeros((64, 50, 3, 3), np.float32), None, _lib.F16)  # cin not a plane multiple
