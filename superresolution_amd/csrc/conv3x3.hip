@@ -21,6 +21,8 @@
 //
 // The kernel is written in bytes: f16, bf16 and f32 differ only in the MFMA issued per pair of
 // 16-byte chunks (one 32x32x16 half MFMA, or four 32x32x2 f32 MFMAs) and in the epilogue casts.
+#include <stdlib.h>
+
 #include "common.h"
 #include "devutil.h"
 
@@ -126,10 +128,76 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
     const int p0 = wave * MB * PW + lx;            // LDS pixel index of (first row of this wave, lx)
     const int bm = (lx >> 2) & 3;                  // weight-row swizzle term (row = 32*k + lx)
 
+#ifdef SRMI_STAMPS
+    unsigned long long* stamp_buf = (unsigned long long*)p.tail_out;
+    int stamp_i = 0;
+#define STAMP()                                                                                   \
+    do {                                                                                          \
+        if (stamp_buf && tid == 0 && stamp_i < 40) {                                              \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            stamp_buf[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 40 + stamp_i++] = t_; \
+        }                                                                                         \
+    } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
     issue(0, 0);
+
+    // Epilogue layout: after the half-wave exchange below a lane owns, for its pixel, the 8
+    // consecutive channels 16*q + 8*lh .. +7 of every 32-channel block (q = 0, 1).  The bias of
+    // those channels is fetched now so that its latency hides behind the main loop.
+    float bias_r[NB][2][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* bp = p.bias + (ct * NB + b) * 32 + 16 * q + 8 * lh;
+            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
+        }
+
     commit(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP();
+
+    // One fragment set = everything the MFMAs of one (dx, k-half) step read from LDS.  Two sets
+    // are alternated so that the ds_reads of step i+1 are in flight while step i multiplies.
+    struct Frag {
+        u32x4 wf[3][NB];
+        u32x4 pf[MB + 2];
+    };
+    auto load_frag = [&](Frag& f, const char* Ab, const char* Bb, const int step) {
+        const int dx = step >> 1, c = 2 * (step & 1) + lh;
+#pragma unroll
+        for (int rho = 0; rho < MB + 2; ++rho) {
+            if (rho < 3) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    f.wf[rho][b] = *(const u32x4*)(Bb + ((rho * 3 + dx) * 32 * NB + b * 32) * 64 + ((c ^ bm) << 4));
+            }
+            const int pp = p0 + rho * PW + dx;
+            f.pf[rho] = *(const u32x4*)(Ab + pp * 64 + (((c ^ (pp >> 2)) & 3) << 4));
+        }
+    };
+    // part 0: the MFMAs of the first patch row (they only need wf[0] and pf[0]); part 1: the rest
+    auto mma_frag = [&](const Frag& f, const int part) {
+#pragma unroll
+        for (int rho = 0; rho < MB + 2; ++rho) {
+            if ((rho == 0) != (part == 0)) continue;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = rho - dy;
+                if (r >= 0 && r < MB) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) mma_chunk<DT>(acc[r][b], f.wf[dy][b], f.pf[rho]);
+                }
+            }
+        }
+    };
 
     for (int cb = 0; cb < p.ncb; ++cb) {
         const int cur = cb & 1;
@@ -138,133 +206,166 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
 
         const char* Ab = smem + cur * A_BYTES;
         const char* Bb = smem + 2 * A_BYTES + cur * B_BYTES + lx * 64;
+        // Per step: the first MFMAs of the current set make the compiler wait for that set alone
+        // (nothing else is outstanding yet); then the next set's ds_reads are issued and run
+        // under the remaining MFMAs, so the following step's wait finds them complete.
+        Frag f0, f1;
+        load_frag(f0, Ab, Bb, 0);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int c = 2 * s + lh;
-                u32x4 wf[3][NB];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-                        wf[dy][b] = *(const u32x4*)(Bb + ((dy * 3 + dx) * 32 * NB + b * 32) * 64 +
-                                                    ((c ^ bm) << 4));
-#pragma unroll
-                for (int rho = 0; rho < MB + 2; ++rho) {
-                    const int pp = p0 + rho * PW + dx;
-                    const u32x4 pf = *(const u32x4*)(Ab + pp * 64 + (((c ^ (pp >> 2)) & 3) << 4));
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int r = rho - dy;
-                        if (r >= 0 && r < MB) {
-#pragma unroll
-                            for (int b = 0; b < NB; ++b) mma_chunk<DT>(acc[r][b], wf[dy][b], pf);
-                        }
-                    }
-                }
-            }
+        for (int st = 0; st < 6; st += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(f1, Ab, Bb, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 2 < 6) load_frag(f0, Ab, Bb, st + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f1, 1);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP();
 
         if (more) commit(cur ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        STAMP();
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
     const int x = x0 + lx;
-    float csum[NB][16];
+    const bool tail = p.tail_mode != SRMI_TAIL_NONE;
+    float csum[NB][2][8];
     if (p.chansum) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) csum[b][i] = 0.f;
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) csum[b][q][j] = 0.f;
     }
     const int ow = p.w * p.ps_r;
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
         const int y = y0 + wave * MB + r;
         const bool inside = (y < p.h) && (x < p.w);
-        const long long pix = (long long)y * p.w + x;
+        const long long pix = inside ? (long long)y * p.w + x : 0;   // dead lanes read pixel 0
+        float v[NB][2][8];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cq = (ct * NB + b) * 32 + 8 * g + 4 * lh;
-                float v[4];
-                {
-                    const f32x4 bias = *(const f32x4*)(p.bias + cq);
+            for (int q = 0; q < 2; ++q) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[r][b][4 * g + j] + bias[j];
+                for (int j = 0; j < 4; ++j) {
+                    // half-wave exchange: lanes 0-31 keep group 2q and receive the partner's,
+                    // lanes 32-63 receive the partner's group 2q+1 and keep their own
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r][b][8 * q + j]),
+                                                                     __float_as_uint(acc[r][b][8 * q + 4 + j]),
+                                                                     false, false);
+                    v[b][q][j] = __uint_as_float(sw[0]) + bias_r[b][q][j];
+                    v[b][q][4 + j] = __uint_as_float(sw[1]) + bias_r[b][q][4 + j];
                 }
                 if (p.act == SRMI_ACT_RELU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = fmaxf(v[b][q][j], 0.f);
                 } else if (p.act == SRMI_ACT_LRELU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] >= 0.f ? v[j] : v[j] * 0.2f;
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] >= 0.f ? v[b][q][j] : v[b][q][j] * 0.2f;
                 }
-                const bool live = inside && cq < p.cout_real;
-                if (p.res1.ptr && live) {
-                    float q[4];
-                    load4(p.res1, n, pix, cq, q);
+            }
+        if (p.res1.ptr) {
+            float rr[NB][2][8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * p.alpha + q[j];
-                }
-                if (p.res2.ptr && live) {
-                    float q[4];
-                    load4(p.res2, n, pix, cq, q);
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * p.beta + q[j];
-                }
-                if (p.out.ptr && live) {
-                    if (p.ps_r == 1) {
-                        store4(p.out, n, pix, cq, v);
-                    } else {
-                        const int ij = cq / p.ps_c, cc = cq - ij * p.ps_c;
-                        const int oy = y * p.ps_r + ij / p.ps_r, ox = x * p.ps_r + ij % p.ps_r;
-                        store4(p.out, n, (long long)oy * ow + ox, cc, v);
-                    }
-                }
-                if (p.out2.ptr && live) store4(p.out2, n, pix, cq, v);
-                if (p.chansum) {
+                for (int q = 0; q < 2; ++q) load8(p.res1, n, pix, (ct * NB + b) * 32 + 16 * q + 8 * lh, rr[b][q]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) csum[b][4 * g + j] += live ? v[j] : 0.f;
-                }
-                if (p.tail_mode != SRMI_TAIL_NONE && b == 0 && g == 0 && lh == 0 && inside && ct == 0) {
-                    float rgb[3];
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        rgb[k] = p.tail_mat[3 * k] * v[0] + p.tail_mat[3 * k + 1] * v[1] +
-                                 p.tail_mat[3 * k + 2] * v[2] + p.tail_bias[k];
-                    if (p.tail_mode == SRMI_TAIL_F32_NCHW) {
-                        float* o = (float*)p.tail_out + (long long)n * 3 * p.h * p.w + pix;
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) o[(long long)k * p.h * p.w] = rgb[k];
-                    } else {
-                        unsigned char* o = (unsigned char*)p.tail_out + ((long long)n * p.h * p.w + pix) * 3;
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] * p.alpha + rr[b][q][j];
+        }
+        if (p.res2.ptr) {
+            float rr[NB][2][8];
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            o[k] = to_u8(rgb[k], p.tail_lo, p.tail_hi, p.tail_scale, p.tail_round);
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) load8(p.res2, n, pix, (ct * NB + b) * 32 + 16 * q + 8 * lh, rr[b][q]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] * p.beta + rr[b][q][j];
+        }
+        if (inside && !tail) {
+            if (p.out.ptr) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int cq = (ct * NB + b) * 32 + 16 * q + 8 * lh;
+                        if (p.ps_r == 1) {
+                            store8(p.out, n, pix, cq, v[b][q]);
+                        } else {
+                            const int ij = cq / p.ps_c, cc = cq - ij * p.ps_c;
+                            const int oy = y * p.ps_r + ij / p.ps_r, ox = x * p.ps_r + ij % p.ps_r;
+                            store8(p.out, n, (long long)oy * ow + ox, cc, v[b][q]);
                         }
                     }
-                }
+            }
+            if (p.out2.ptr) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) store8(p.out2, n, pix, (ct * NB + b) * 32 + 16 * q + 8 * lh, v[b][q]);
+            }
+        }
+        if (p.chansum) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) csum[b][q][j] += inside ? v[b][q][j] : 0.f;
+        }
+        if (tail && inside && lh == 0 && ct == 0) {
+            float rgb[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                rgb[k] = p.tail_mat[3 * k] * v[0][0][0] + p.tail_mat[3 * k + 1] * v[0][0][1] +
+                         p.tail_mat[3 * k + 2] * v[0][0][2] + p.tail_bias[k];
+            if (p.tail_mode == SRMI_TAIL_F32_NCHW) {
+                float* o = (float*)p.tail_out + (long long)n * 3 * p.h * p.w + pix;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[(long long)k * p.h * p.w] = rgb[k];
+            } else {
+                unsigned char* o = (unsigned char*)p.tail_out + ((long long)n * p.h * p.w + pix) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[k] = to_u8(rgb[k], p.tail_lo, p.tail_hi, p.tail_scale, p.tail_round);
             }
         }
     }
 
+    STAMP();
     if (p.chansum) {
         // deterministic tile sums: lanes -> wave (xor shuffles inside each 32-lane half), waves -> LDS
         float* red = (float*)smem;  // [4 waves][32*NB]; the pixel patch is no longer needed
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float s = csum[b][i];
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m);
-                if (lx == 0) red[wave * 32 * NB + b * 32 + 8 * (i >> 2) + 4 * lh + (i & 3)] = s;
-            }
+                for (int j = 0; j < 8; ++j) {
+                    float s = csum[b][q][j];
+#pragma unroll
+                    for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m);
+                    if (lx == 0) red[wave * 32 * NB + b * 32 + 16 * q + 8 * lh + j] = s;
+                }
         __syncthreads();
         if (tid < 32 * NB) {
             const float s = (red[tid] + red[32 * NB + tid]) + (red[2 * 32 * NB + tid] + red[3 * 32 * NB + tid]);
@@ -363,6 +464,9 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.out = to_view(d->out); p.out2 = to_view(d->out2);
     p.chansum = d->chansum;
     p.tail_out = d->tail_out;
+#ifdef SRMI_STAMPS
+    if (d->tail_mode == SRMI_TAIL_NONE) p.tail_out = getenv("SRMI_STAMP_PTR") ? (void*)strtoull(getenv("SRMI_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
     for (int i = 0; i < 9; ++i) p.tail_mat[i] = d->tail_mat[i];
     for (int i = 0; i < 3; ++i) p.tail_bias[i] = d->tail_bias[i];
     p.tail_lo = d->tail_lo; p.tail_hi = d->tail_hi; p.tail_scale = d->tail_scale;

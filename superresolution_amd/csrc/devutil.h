@@ -49,6 +49,43 @@ __device__ __forceinline__ void store4(const TView& t, int n, long long pix, int
     }
 }
 
+// ---- 8-channel accessors: channel c is a multiple of 8; 16 bytes for halves, 32 for floats ------
+__device__ __forceinline__ void load8(const TView& t, int n, long long pix, int c, float (&v)[8]) {
+    const char* a = chan_addr(t, n, pix, c);
+    if (t.dtype == SRMI_F32) {
+        const f32x4 x0 = *(const f32x4*)a, x1 = *(const f32x4*)(a + 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+    } else if (t.dtype == SRMI_F16) {
+        const f16x8 x = *(const f16x8*)a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    } else {
+        const bf16x8 x = *(const bf16x8*)a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    }
+}
+
+__device__ __forceinline__ void store8(const TView& t, int n, long long pix, int c, const float (&v)[8]) {
+    char* a = chan_addr(t, n, pix, c);
+    if (t.dtype == SRMI_F32) {
+        const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)a = x0;
+        *(f32x4*)(a + 16) = x1;
+    } else if (t.dtype == SRMI_F16) {
+        f16x8 x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (_Float16)v[j];
+        *(f16x8*)a = x;
+    } else {
+        bf16x8 x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (__bf16)v[j];
+        *(bf16x8*)a = x;
+    }
+}
+
 // clamp -> scale -> round to the u8 grid; separate roundings for the multiply and the +0.5 (no
 // fused multiply-add), as the scalar host code of the runners computes them.
 __device__ __forceinline__ unsigned char to_u8(float v, float lo, float hi, float scale, int mode) {
