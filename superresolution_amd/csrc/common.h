@@ -60,6 +60,7 @@ struct ConvParams {
     int ps_r, ps_c;       // pixel-shuffle factor and channels after the shuffle
     int tiles_x, tiles_y;
     int tail_mode, tail_round;
+    unsigned in_plane_bytes;  // bytes of one plane of the input tensor (descriptor range)
     TView in;
     const char* wpk;
     const float* bias;

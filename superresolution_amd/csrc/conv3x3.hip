@@ -2,21 +2,26 @@
 // tails fused into the epilogue.
 //
 // Work decomposition
-//   workgroup  = 256 threads (4 waves, one per SIMD) -> a spatial tile of (4*MB) rows x 32 columns
-//                of one image and a tile of 32*NB output channels.
+//   workgroup  = 256 threads (4 waves) -> a spatial tile of (4*MB) rows x 32 columns of one image
+//                and a tile of 32*NB output channels.  LDS use is kept below 80 KiB so that at
+//                least two workgroups share a CU: one workgroup's loads, barriers and epilogue
+//                stores run under the other's MFMAs.
 //   wave       = MB consecutive rows of the tile (one row of 32 pixels = one MFMA column block)
 //                x NB blocks of 32 output channels: MB*NB accumulators of 32x32 (f32).
 //   MFMA roles = A operand: weights (rows = output channel), B operand: pixels (columns), so a lane
-//                ends up holding 4 consecutive output channels of ONE pixel per register group and
-//                the epilogue reads residuals / writes results with 8- or 16-byte accesses.
+//                ends up holding output channels of ONE pixel and the epilogue reads residuals and
+//                writes results with 16-byte accesses.
 //
-// Data movement per input-channel block (one 64-byte-per-pixel plane = 32 halves or 16 floats):
-//   weights   : pre-swizzled on the host into exactly the LDS image; copied global -> LDS by LDS-DMA
-//               (global_load_lds, 16 B per lane), no registers involved.
-//   pixels    : (4*MB+2) x 34 halo patch, 16-byte chunks gathered global -> VGPR -> LDS so that
-//               out-of-image chunks become zeros and nearest-x2 upsampling is a pure address map.
-//   both are double buffered: block cb+1 is in flight while block cb feeds the MFMAs.
-// LDS rows are 64 bytes; the 16-byte chunk index is XORed with (row>>2)&3 so that the 16-lane
+// Data movement: the reduction over input channels runs in STAGES of 32 bytes of channels per
+// pixel (16 halves or 8 floats = half a plane).  Per stage both operands are copied
+// global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs):
+//   weights   : pre-swizzled on the host into exactly the LDS image, a linear copy;
+//   pixels    : (4*MB+2) x 34 halo patch; the per-lane source offset is computed once per
+//               workgroup, out-of-image lanes carry an offset beyond the buffer descriptor's range
+//               and therefore read zeros (= the convolution's zero padding); nearest-x2
+//               upsampling is a pure address map.
+// Stages are double buffered: stage s+1 is in flight while stage s feeds the MFMAs.
+// LDS rows are 32 bytes; the 16-byte chunk index is XORed with (row>>3)&1 so that the 16-lane
 // groups of ds_read_b128 touch 16 different bank slots (conflict-free).
 //
 // The kernel is written in bytes: f16, bf16 and f32 differ only in the MFMA issued per pair of
@@ -46,15 +51,32 @@ __device__ __forceinline__ void mma_chunk(f32x16& c, const u32x4& wfrag, const u
     }
 }
 
+template <int MB, int NB>
+struct ConvGeom {
+    static constexpr int TH = 4 * MB, PH = TH + 2, PW = kPatchW;
+    static constexpr int NCH = PH * PW * 2;                // 16-byte chunks of one pixel-patch stage
+    static constexpr int A_PIECES = (NCH + 63) / 64;       // 1-KiB LDS-DMA pieces
+    static constexpr int A_BYTES = A_PIECES * 1024;
+    static constexpr int B_BYTES = 9 * 32 * NB * 32;       // weight image of one stage
+    static constexpr int B_PIECES = B_BYTES / 1024;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+};
+
+constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // beyond every descriptor's num_records -> reads 0
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+#endif
+
 template <int DT, int MB, int NB>
-__global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
-    constexpr int TH = 4 * MB, PH = TH + 2, PW = kPatchW;
-    constexpr int A_BYTES = PH * PW * 64;
-    constexpr int B_BYTES = 9 * 32 * NB * 64;
-    constexpr int NCH = PH * PW * 4;               // 16-byte chunks of the pixel patch
-    constexpr int NLD = (NCH + 255) / 256;         // chunks per thread
-    constexpr int NPIECE = B_BYTES / 1024;         // 1-KiB LDS-DMA pieces of the weight image
-    constexpr int NPW = (NPIECE + 3) / 4;
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
+    using G = ConvGeom<MB, NB>;
+    constexpr int TH = G::TH, PW = G::PW;
+    constexpr int APW = (G::A_PIECES + 3) / 4, BPW = (G::B_PIECES + 3) / 4;  // pieces per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -66,53 +88,49 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
     const int x0 = tx * kTileW, y0 = ty * TH;
     const int ct = blockIdx.y;
     const int n = blockIdx.z;
+    const int nstage = 2 * p.ncb;
 
-    // ---- per-thread gather map of the pixel patch (identical for every channel block) ----------
-    unsigned aoff[NLD];
-    unsigned amask = 0;
+    // ---- per-lane source offsets of the pixel patch (identical for every stage) ----------------
+    // LDS chunk i holds logical chunk c = (i&1) ^ ((pixel>>3)&1) of patch pixel i>>1.
+    unsigned aoff[APW];
     {
         const int srcW = p.in_up2 ? (p.w >> 1) : p.w;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + 256 * k;
-            const int pp = i >> 2, cs = i & 3;
-            const int c = cs ^ ((pp >> 2) & 3);
+        for (int j = 0; j < APW; ++j) {
+            const int i = (wave + 4 * j) * 64 + lane;
+            const int pp = i >> 1;
+            const int c = (i & 1) ^ ((pp >> 3) & 1);
             const int rho = pp / PW, xi = pp - rho * PW;
             int gy = y0 - 1 + rho, gx = x0 - 1 + xi;
-            const bool ok = (i < NCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+            const bool ok = (i < G::NCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
             if (p.in_up2) { gy >>= 1; gx >>= 1; }
-            aoff[k] = ok ? ((unsigned)(gy * srcW + gx) * 64u + (unsigned)c * 16u) : 0u;
-            amask |= ok ? (1u << k) : 0u;
+            aoff[j] = ok ? ((unsigned)(gy * srcW + gx) * 64u + (unsigned)c * 16u) : kOobOffset;
         }
     }
     const char* in_img = p.in.ptr + (long long)n * p.in.img_stride_b;
-    const char* w_tile = p.wpk + (size_t)ct * p.ncb * B_BYTES;
+    const char* w_tile = p.wpk + (size_t)ct * nstage * G::B_BYTES;
+    const unsigned plane_bytes = p.in_plane_bytes;
 
-    u32x4 areg[NLD];
-    auto issue = [&](int cb, int buf) {
-        const char* wsrc = w_tile + (size_t)cb * B_BYTES + lane * 16;
-        char* bdst = smem + 2 * A_BYTES + buf * B_BYTES;
+    // stage s = (channel block s>>1, half s&1): 32 bytes of channels per pixel
+    auto issue = [&](int s, int buf) {
+        char* abuf = smem + buf * G::STAGE_BYTES;
+        char* bbuf = abuf + G::A_BYTES;
+        const auto ra = make_rsrc(in_img + (long long)(s >> 1) * p.in.plane_stride_b + (s & 1) * 32,
+                                  plane_bytes - (s & 1) * 32);
+        const auto rb = make_rsrc(w_tile + (size_t)s * G::B_BYTES, G::B_BYTES);
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) {
+        for (int j = 0; j < APW; ++j) {
             const int k = wave + 4 * j;
-            if (k < NPIECE)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(wsrc + k * 1024),
-                    (__attribute__((address_space(3))) void*)(bdst + k * 1024), 16, 0, 0);
+            if (k < G::A_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(abuf + k * 1024),
+                                                         16, aoff[j], 0, 0, 0);
         }
-        const char* src = in_img + (long long)cb * p.in.plane_stride_b;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            areg[k] = ((amask >> k) & 1u) ? *(const u32x4*)(src + aoff[k]) : z;
-        }
-    };
-    auto commit = [&](int buf) {
-        char* adst = smem + buf * A_BYTES;
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + 256 * k;
-            if (i < NCH) *(u32x4*)(adst + i * 16) = areg[k];
+        for (int j = 0; j < BPW; ++j) {
+            const int k = wave + 4 * j;
+            if (k < G::B_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(bbuf + k * 1024),
+                                                         16, k * 1024 + lane * 16, 0, 0, 0);
         }
     };
 
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
 
     const int lx = lane & 31, lh = lane >> 5;
     const int p0 = wave * MB * PW + lx;            // LDS pixel index of (first row of this wave, lx)
-    const int bm = (lx >> 2) & 3;                  // weight-row swizzle term (row = 32*k + lx)
+    const int bm = (lx >> 3) & 1;                  // weight-row swizzle term (row = 32*k + lx)
 
 #ifdef SRMI_STAMPS
     unsigned long long* stamp_buf = (unsigned long long*)p.tail_out;
@@ -144,43 +162,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
 #endif
     STAMP();
     issue(0, 0);
-
-    // Epilogue layout: after the half-wave exchange below a lane owns, for its pixel, the 8
-    // consecutive channels 16*q + 8*lh .. +7 of every 32-channel block (q = 0, 1).  The bias of
-    // those channels is fetched now so that its latency hides behind the main loop.
-    float bias_r[NB][2][8];
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float* bp = p.bias + (ct * NB + b) * 32 + 16 * q + 8 * lh;
-            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
-        }
-
-    commit(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STAMP();
 
-    // One fragment set = everything the MFMAs of one (dx, k-half) step read from LDS.  Two sets
+    // One fragment set = everything the MFMAs of one horizontal tap (dx) read from LDS.  Two sets
     // are alternated so that the ds_reads of step i+1 are in flight while step i multiplies.
     struct Frag {
         u32x4 wf[3][NB];
         u32x4 pf[MB + 2];
     };
-    auto load_frag = [&](Frag& f, const char* Ab, const char* Bb, const int step) {
-        const int dx = step >> 1, c = 2 * (step & 1) + lh;
+    auto load_frag = [&](Frag& f, const char* Ab, const char* Bb, const int dx) {
 #pragma unroll
         for (int rho = 0; rho < MB + 2; ++rho) {
             if (rho < 3) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    f.wf[rho][b] = *(const u32x4*)(Bb + ((rho * 3 + dx) * 32 * NB + b * 32) * 64 + ((c ^ bm) << 4));
+                    f.wf[rho][b] = *(const u32x4*)(Bb + ((rho * 3 + dx) * 32 * NB + b * 32) * 32 + ((lh ^ bm) << 4));
             }
             const int pp = p0 + rho * PW + dx;
-            f.pf[rho] = *(const u32x4*)(Ab + pp * 64 + (((c ^ (pp >> 2)) & 3) << 4));
+            f.pf[rho] = *(const u32x4*)(Ab + pp * 32 + (((lh ^ (pp >> 3)) & 1) << 4));
         }
     };
     // part 0: the MFMAs of the first patch row (they only need wf[0] and pf[0]); part 1: the rest
@@ -199,45 +200,55 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
         }
     };
 
-    for (int cb = 0; cb < p.ncb; ++cb) {
-        const int cur = cb & 1;
-        const bool more = cb + 1 < p.ncb;
-        if (more) issue(cb + 1, cur ^ 1);
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nstage) issue(s + 1, cur ^ 1);
 
-        const char* Ab = smem + cur * A_BYTES;
-        const char* Bb = smem + 2 * A_BYTES + cur * B_BYTES + lx * 64;
+        const char* Ab = smem + cur * G::STAGE_BYTES;
+        const char* Bb = Ab + G::A_BYTES + lx * 32;
         // Per step: the first MFMAs of the current set make the compiler wait for that set alone
         // (nothing else is outstanding yet); then the next set's ds_reads are issued and run
         // under the remaining MFMAs, so the following step's wait finds them complete.
         Frag f0, f1;
         load_frag(f0, Ab, Bb, 0);
-#pragma unroll
-        for (int st = 0; st < 6; st += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            mma_frag(f0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frag(f1, Ab, Bb, st + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_frag(f0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_frag(f1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (st + 2 < 6) load_frag(f0, Ab, Bb, st + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_frag(f1, 1);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag(f0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag(f1, Ab, Bb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag(f0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag(f1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag(f0, Ab, Bb, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag(f1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag(f0, 0);
+        mma_frag(f0, 1);
         __builtin_amdgcn_sched_barrier(0);
         STAMP();
 
-        if (more) commit(cur ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         STAMP();
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
+    // Epilogue layout: after the half-wave exchange below a lane owns, for its pixel, the 8
+    // consecutive channels 16*q + 8*lh .. +7 of every 32-channel block (q = 0, 1).
     const int x = x0 + lx;
     const bool tail = p.tail_mode != SRMI_TAIL_NONE;
+    float bias_r[NB][2][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* bp = p.bias + (ct * NB + b) * 32 + 16 * q + 8 * lh;
+            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
+        }
     float csum[NB][2][8];
     if (p.chansum) {
 #pragma unroll
@@ -374,13 +385,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
                 p.chansum[((long long)n * (p.tiles_x * p.tiles_y) + tile) * p.cout_real + cq] = s;
         }
     }
+#endif
 }
 
 // ---- host launcher --------------------------------------------------------------------------------
 template <int DT, int MB, int NB>
 static int launch(const ConvParams& p, hipStream_t stream) {
-    constexpr int TH = 4 * MB;
-    constexpr size_t lds = 2 * ((TH + 2) * kPatchW * 64 + 9 * 32 * NB * 64);
+    constexpr size_t lds = ConvGeom<MB, NB>::LDS_BYTES;
     static bool configured = false;
     if (!configured) {
         SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB>,
@@ -458,6 +469,10 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.tiles_y = (d->h + 4 * mb - 1) / (4 * mb);
     p.tail_mode = d->tail_mode; p.tail_round = d->tail_round;
     p.in = to_view(d->in);
+    {
+        const long long src_px = d->in_up2 ? (long long)(d->h / 2) * (d->w / 2) : (long long)d->h * d->w;
+        p.in_plane_bytes = (unsigned)(src_px * 64);
+    }
     p.wpk = (const char*)d->wpk; p.bias = d->bias;
     p.alpha = d->alpha; p.beta = d->beta;
     p.res1 = to_view(d->res1); p.res2 = to_view(d->res2);

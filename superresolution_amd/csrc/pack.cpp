@@ -1,9 +1,9 @@
 // Host-side repacking of OIHW float32 convolution weights into the LDS image the conv kernel
 // stages with LDS-DMA.
 //
-// Packed layout: [cout tile][cin block][tap = ky*3+kx][row = output channel within tile][64 bytes]
-// where the 64 bytes are the block's input channels (32 halves or 16 floats) as four 16-byte
-// chunks, stored chunk index = logical chunk ^ ((row_in_image >> 2) & 3), row_in_image =
+// Packed layout: [cout tile][stage = (cin block, half)][tap = ky*3+kx][row = output channel within
+// tile][32 bytes] where the 32 bytes are the stage's input channels (16 halves or 8 floats) as two
+// 16-byte chunks, stored chunk index = logical chunk ^ ((row_in_image >> 3) & 1), row_in_image =
 // tap * cout_tile + row.  With pixel-shuffle packing the output channels are permuted so that a
 // 32-channel block holds one (i, j) sub-pixel position of 32 consecutive post-shuffle channels.
 #include <string.h>
@@ -83,19 +83,19 @@ extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, in
     const int r = ps_r <= 1 ? 1 : ps_r;
     if (r > 1 && cout % (r * r * 32)) SRMI_FAIL("srmi_pack_conv3x3: cout=%d incompatible with pixel shuffle %d", cout, r);
     const int cpb = dtype_cpb(dtype), esz = dtype_size(dtype), epc = 16 / esz;  // elements per chunk
-    const int ncb = cin / cpb, ntile = nbias / cout_tile;
+    const int nstage = 2 * (cin / cpb), ntile = nbias / cout_tile;
     char* out = (char*)wpk_out;
     for (int t = 0; t < ntile; ++t)
-        for (int cb = 0; cb < ncb; ++cb)
+        for (int st = 0; st < nstage; ++st)
             for (int tap = 0; tap < 9; ++tap)
                 for (int row = 0; row < cout_tile; ++row) {
                     const int o = packed_to_orig(t * cout_tile + row, cout, r);
                     const int img_row = tap * cout_tile + row;
-                    char* dst_row = out + ((((size_t)t * ncb + cb) * 9 + tap) * cout_tile + row) * 64;
-                    for (int c = 0; c < 4; ++c) {
-                        char* dst = dst_row + ((c ^ ((img_row >> 2) & 3)) << 4);
+                    char* dst_row = out + ((((size_t)t * nstage + st) * 9 + tap) * cout_tile + row) * 32;
+                    for (int c = 0; c < 2; ++c) {
+                        char* dst = dst_row + ((c ^ ((img_row >> 3) & 1)) << 4);
                         for (int e = 0; e < epc; ++e) {
-                            const int ci = cb * cpb + c * epc + e;
+                            const int ci = (st >> 1) * cpb + ((st & 1) * 2 + c) * epc + e;
                             const float v = o < 0 ? 0.f : w[((size_t)o * cin + ci) * 9 + tap];
                             if (dtype == SRMI_F32) {
                                 memcpy(dst + 4 * e, &v, 4);
