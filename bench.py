@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--sweep", type=int, default=1, help="frames swept through each layer together")
+    ap.add_argument("--streams", type=int, default=1, help="independent frame streams per GPU (each its own engine)")
     ap.add_argument("--no-trunk-f32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -111,16 +112,34 @@ def main():
     batch = args.batch or batch
 
     from superresolution_amd import _lib, synth
-    model, sd = build_model(args.model, args.dtype, not args.no_trunk_f32, local_rank)
-    eng = model.engine()
-    eng.set_sweep(args.sweep)
+    models, engs = [], []
+    for _ in range(args.streams):
+        model, sd = build_model(args.model, args.dtype, not args.no_trunk_f32, local_rank)
+        models.append(model)
+        engs.append(model.engine())
+        engs[-1].set_sweep(args.sweep)
+    eng = engs[0]
     scale = eng.scale
     imgs = torch.from_numpy(synth.random_image(h, w, 100 + rank, n=batch)).cuda()
     imgs[0] = torch.from_numpy(synth.smooth_image(h, w, rank)).cuda()
     out = torch.empty((batch, h * scale, w * scale, 3), dtype=torch.uint8, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+    main_stream = torch.cuda.current_stream()
 
     def step():
-        eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
+        if streams is None:
+            eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
+            return
+        # frames are independent: stream i takes frames i, i+S, ... ; the streams fork from and join the
+        # main stream so that the events around the timed region cover all of them
+        for i, st in enumerate(streams):
+            st.wait_stream(main_stream)
+        for j in range(0, batch):
+            i = j % len(streams)
+            with torch.cuda.stream(streams[i]):
+                engs[i].forward_u8(imgs[j:j + 1], _lib.ROUND_HALF_UP, out=out[j:j + 1])
+        for st in streams:
+            main_stream.wait_stream(st)
 
     for _ in range(args.warmup):
         step()
@@ -167,7 +186,7 @@ def main():
                     "official state_dict layout)",
             "config": {"workload": f"{args.model} x{scale} {w}x{h}->{w * scale}x{h * scale}, "
                                    f"{batch} frames per GPU per step, u8 in HBM -> u8 in HBM",
-                       "frames_per_gpu_per_step": batch, "sweep": args.sweep,
+                       "frames_per_gpu_per_step": batch, "sweep": args.sweep, "streams": args.streams,
                        "trunk_f32": not args.no_trunk_f32, "parallelism": f"frame-sharded x{world}, no collective"},
             "ms_per_frame_per_gpu": round(dev_s / (batch * args.steps) * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",

@@ -102,7 +102,7 @@ typedef struct {
     int32_t act;
     int32_t ps_r;        /* 1 (none), 2 or 3 */
     int32_t cout_tile;   /* 32 or 64: output channels per workgroup (must match the packing) */
-    int32_t rows_per_wave; /* 0 = library default; 2, 3 or 4 */
+    int32_t rows_per_wave; /* 0 = library default; 2, 3, or (cout_tile 32 only) 4 */
     int32_t tail_mode;   /* SRMI_TAIL_* */
     srmi_tensor_t in;
     const void* wpk;     /* packed weights (device) */
@@ -238,6 +238,10 @@ int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* out, int n, 
  * clamp(v + mean*range, 0, 255) (edsr.cpp:21-41,101-122). */
 int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
                           int round_mode, void* hip_stream);
+/* u8 runner path of a Core (no-MeanShift) EDSR / RCAN model: subtract shift[c] (= mean*range)
+ * before the first conv and add it back after the last one (edsr.cpp:36-37,116).  No effect on
+ * full models (their MeanShift tensors are used) or RRDBNet. */
+int srmi_model_set_rgb_shift(srmi_model_t* m, const float* shift);
 /* Bytes of device workspace currently held by the model (grows with the largest n*h*w seen). */
 size_t srmi_model_workspace_bytes(const srmi_model_t* m);
 /* Images a forward call sweeps through each layer together (default 1: one image per

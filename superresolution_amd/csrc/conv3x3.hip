@@ -60,16 +60,246 @@ struct ConvGeom {
     static constexpr int B_BYTES = 9 * 32 * NB * 32;       // weight image of one stage
     static constexpr int B_PIECES = B_BYTES / 1024;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // + 32*NB floats of bias behind it
+    static constexpr int LDS_TOTAL = LDS_BYTES + 32 * NB * 4;
 };
 
-constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // beyond every descriptor's num_records -> reads 0
+#define SRMI_OOB_OFFSET 0xFFFFFFF0u  // beyond every descriptor's num_records -> reads 0
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
 }
 #endif
+
+// ---- epilogue ------------------------------------------------------------------------------------
+struct EpiCtx {
+    int n, ct, tile, x0, y0, wave, lx, lh, tid;
+};
+
+constexpr int kAnyType = 99;  // dtype resolved at run time (generic path)
+
+// 8 consecutive channels (c % 8 == 0) of one pixel; TYPE is a dtype code, kAnyType, or -1 (absent)
+template <int TYPE>
+__device__ __forceinline__ void ld8(const TView& t, int n, long long pix, int c, float (&v)[8]) {
+    if constexpr (TYPE == kAnyType) {
+        load8(t, n, pix, c, v);
+    } else if constexpr (TYPE == SRMI_F32) {
+        const char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 64 + (c & 15) * 4;
+        const f32x4 x0 = *(const f32x4*)a, x1 = *(const f32x4*)(a + 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+    } else {
+        const char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 5) * t.plane_stride_b + pix * 64 + (c & 31) * 2;
+        if constexpr (TYPE == SRMI_F16) {
+            const f16x8 x = *(const f16x8*)a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+        } else {
+            const bf16x8 x = *(const bf16x8*)a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+        }
+    }
+}
+
+template <int TYPE>
+__device__ __forceinline__ void st8(const TView& t, int n, long long pix, int c, const float (&v)[8]) {
+    if constexpr (TYPE == kAnyType) {
+        store8(t, n, pix, c, v);
+    } else if constexpr (TYPE == SRMI_F32) {
+        char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 64 + (c & 15) * 4;
+        const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)a = x0;
+        *(f32x4*)(a + 16) = x1;
+    } else {
+        char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 5) * t.plane_stride_b + pix * 64 + (c & 31) * 2;
+        if constexpr (TYPE == SRMI_F16) {
+            f16x8 x;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (_Float16)v[j];
+            *(f16x8*)a = x;
+        } else {
+            bf16x8 x;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (__bf16)v[j];
+            *(bf16x8*)a = x;
+        }
+    }
+}
+
+// After the half-wave exchange a lane owns, for its pixel, the 8 consecutive channels
+// 16*q + 8*lh .. +7 of every 32-channel block (q = 0, 1): all tensor accesses are 16 or 32 bytes.
+template <int DT, int MB, int NB, int OUT, int RES, bool RES2, int OUT2>
+__device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f32x16 (&acc)[MB][NB],
+                                         const float* lds_bias, float* lds_red) {
+    constexpr bool generic = OUT == kAnyType;
+    const int x = k.x0 + k.lx;
+    const bool tail = generic && p.tail_mode != SRMI_TAIL_NONE;
+    float bias_r[NB][2][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* bp = lds_bias + b * 32 + 16 * q + 8 * k.lh;
+            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
+        }
+    float csum[NB][2][8];
+    if (p.chansum) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) csum[b][q][j] = 0.f;
+    }
+    const int ow = p.w * p.ps_r;
+    const bool has_res1 = generic ? p.res1.ptr != nullptr : RES != -1;
+    const bool has_res2 = generic ? p.res2.ptr != nullptr : RES2;
+    const bool has_out = generic ? p.out.ptr != nullptr : OUT != -1;
+    const bool has_out2 = generic ? p.out2.ptr != nullptr : OUT2 != -1;
+#pragma unroll
+    for (int r = 0; r < MB; ++r) {
+        const int y = k.y0 + k.wave * MB + r;
+        const bool inside = (y < p.h) && (x < p.w);
+        const long long pix = inside ? (long long)y * p.w + x : 0;   // dead lanes read pixel 0
+        float v[NB][2][8];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // half-wave exchange: lanes 0-31 keep group 2q and receive the partner's,
+                    // lanes 32-63 receive the partner's group 2q+1 and keep their own
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r][b][8 * q + j]),
+                                                                     __float_as_uint(acc[r][b][8 * q + 4 + j]),
+                                                                     false, false);
+                    v[b][q][j] = __uint_as_float(sw[0]) + bias_r[b][q][j];
+                    v[b][q][4 + j] = __uint_as_float(sw[1]) + bias_r[b][q][4 + j];
+                }
+            }
+        if (p.act == SRMI_ACT_RELU) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = fmaxf(v[b][q][j], 0.f);
+        } else if (p.act == SRMI_ACT_LRELU) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] >= 0.f ? v[b][q][j] : v[b][q][j] * 0.2f;
+        }
+        if (has_res1) {
+            float rr[NB][2][8];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ld8<RES>(p.res1, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, rr[b][q]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] * p.alpha + rr[b][q][j];
+        }
+        if (has_res2) {
+            float rr[NB][2][8];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ld8<RES>(p.res2, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, rr[b][q]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] * p.beta + rr[b][q][j];
+        }
+        if (inside && !tail) {
+            if (has_out) {
+                if (p.ps_r == 1) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            st8<OUT>(p.out, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, v[b][q]);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int cq = (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh;
+                            const int ij = cq / p.ps_c, cc = cq - ij * p.ps_c;
+                            const int oy = y * p.ps_r + ij / p.ps_r, ox = x * p.ps_r + ij % p.ps_r;
+                            st8<OUT>(p.out, k.n, (long long)oy * ow + ox, cc, v[b][q]);
+                        }
+                }
+            }
+            if (has_out2) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        st8<OUT2>(p.out2, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, v[b][q]);
+            }
+        }
+        if (p.chansum) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) csum[b][q][j] += inside ? v[b][q][j] : 0.f;
+        }
+        if (tail && inside && k.lh == 0 && k.ct == 0) {
+            float rgb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                rgb[c] = p.tail_mat[3 * c] * v[0][0][0] + p.tail_mat[3 * c + 1] * v[0][0][1] +
+                         p.tail_mat[3 * c + 2] * v[0][0][2] + p.tail_bias[c];
+            if (p.tail_mode == SRMI_TAIL_F32_NCHW) {
+                float* o = (float*)p.tail_out + (long long)k.n * 3 * p.h * p.w + pix;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[(long long)c * p.h * p.w] = rgb[c];
+            } else {
+                unsigned char* o = (unsigned char*)p.tail_out + ((long long)k.n * p.h * p.w + pix) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[c] = to_u8(rgb[c], p.tail_lo, p.tail_hi, p.tail_scale, p.tail_round);
+            }
+        }
+    }
+
+    if (p.chansum) {
+        // deterministic tile sums: lanes -> wave (xor shuffles inside each 32-lane half), waves -> LDS
+        // (lds_red aliases the stage buffers, which nobody reads any more)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float s = csum[b][q][j];
+#pragma unroll
+                    for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m);
+                    if (k.lx == 0) lds_red[k.wave * 32 * NB + b * 32 + 16 * q + 8 * k.lh + j] = s;
+                }
+        __syncthreads();
+        if (k.tid < 32 * NB) {
+            const float s = (lds_red[k.tid] + lds_red[32 * NB + k.tid]) +
+                            (lds_red[2 * 32 * NB + k.tid] + lds_red[3 * 32 * NB + k.tid]);
+            const int cq = k.ct * 32 * NB + k.tid;
+            if (cq < p.cout_real)
+                p.chansum[((long long)k.n * (p.tiles_x * p.tiles_y) + k.tile) * p.cout_real + cq] = s;
+        }
+    }
+}
 
 template <int DT, int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
@@ -104,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
             int gy = y0 - 1 + rho, gx = x0 - 1 + xi;
             const bool ok = (i < G::NCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
             if (p.in_up2) { gy >>= 1; gx >>= 1; }
-            aoff[j] = ok ? ((unsigned)(gy * srcW + gx) * 64u + (unsigned)c * 16u) : kOobOffset;
+            aoff[j] = ok ? ((unsigned)(gy * srcW + gx) * 64u + (unsigned)c * 16u) : SRMI_OOB_OFFSET;
         }
     }
     const char* in_img = p.in.ptr + (long long)n * p.in.img_stride_b;
@@ -162,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
 #endif
     STAMP();
     issue(0, 0);
+    if (tid < 32 * NB) ((float*)(smem + G::LDS_BYTES))[tid] = p.bias[ct * 32 * NB + tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STAMP();
@@ -235,163 +466,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
-    // Epilogue layout: after the half-wave exchange below a lane owns, for its pixel, the 8
-    // consecutive channels 16*q + 8*lh .. +7 of every 32-channel block (q = 0, 1).
-    const int x = x0 + lx;
-    const bool tail = p.tail_mode != SRMI_TAIL_NONE;
-    float bias_r[NB][2][8];
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float* bp = p.bias + (ct * NB + b) * 32 + 16 * q + 8 * lh;
-            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
-        }
-    float csum[NB][2][8];
-    if (p.chansum) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) csum[b][q][j] = 0.f;
+    // One uniform switch selects straight-line code specialised for the tensor types in use; the
+    // combinations the networks need are compiled, anything else takes the generic path.
+    const EpiCtx ctx{n, ct, tile, x0, y0, wave, lx, lh, tid};
+    const float* lds_bias = (const float*)(smem + G::LDS_BYTES);
+    float* lds_red = (float*)smem;
+    const int od = p.out.ptr ? p.out.dtype : -1, rd = p.res1.ptr ? p.res1.dtype : -1;
+    const int r2 = p.res2.ptr ? p.res2.dtype : -1, o2 = p.out2.ptr ? p.out2.dtype : -1;
+    const bool plain_io = p.tail_mode == SRMI_TAIL_NONE && od == DT && (r2 == -1 || r2 == rd);
+    if (plain_io && rd == -1 && o2 == -1) {
+        epilogue<DT, MB, NB, DT, -1, false, -1>(p, ctx, acc, lds_bias, lds_red);
+    } else if (plain_io && rd == SRMI_F32 && r2 == -1 && o2 == -1) {
+        epilogue<DT, MB, NB, DT, SRMI_F32, false, -1>(p, ctx, acc, lds_bias, lds_red);
+    } else if (plain_io && rd == SRMI_F32 && r2 == -1 && o2 == SRMI_F32) {
+        epilogue<DT, MB, NB, DT, SRMI_F32, false, SRMI_F32>(p, ctx, acc, lds_bias, lds_red);
+    } else if (plain_io && rd == SRMI_F32 && r2 == SRMI_F32 && o2 == SRMI_F32) {
+        epilogue<DT, MB, NB, DT, SRMI_F32, true, SRMI_F32>(p, ctx, acc, lds_bias, lds_red);
+    } else if (plain_io && rd == DT && r2 == -1 && o2 == -1) {
+        epilogue<DT, MB, NB, DT, DT, false, -1>(p, ctx, acc, lds_bias, lds_red);
+    } else if (plain_io && rd == DT && r2 == -1 && o2 == DT) {
+        epilogue<DT, MB, NB, DT, DT, false, DT>(p, ctx, acc, lds_bias, lds_red);
+    } else if (plain_io && rd == DT && r2 == DT && o2 == DT) {
+        epilogue<DT, MB, NB, DT, DT, true, DT>(p, ctx, acc, lds_bias, lds_red);
+    } else {
+        epilogue<DT, MB, NB, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc, lds_bias, lds_red);
     }
-    const int ow = p.w * p.ps_r;
-#pragma unroll
-    for (int r = 0; r < MB; ++r) {
-        const int y = y0 + wave * MB + r;
-        const bool inside = (y < p.h) && (x < p.w);
-        const long long pix = inside ? (long long)y * p.w + x : 0;   // dead lanes read pixel 0
-        float v[NB][2][8];
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // half-wave exchange: lanes 0-31 keep group 2q and receive the partner's,
-                    // lanes 32-63 receive the partner's group 2q+1 and keep their own
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r][b][8 * q + j]),
-                                                                     __float_as_uint(acc[r][b][8 * q + 4 + j]),
-                                                                     false, false);
-                    v[b][q][j] = __uint_as_float(sw[0]) + bias_r[b][q][j];
-                    v[b][q][4 + j] = __uint_as_float(sw[1]) + bias_r[b][q][4 + j];
-                }
-                if (p.act == SRMI_ACT_RELU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[b][q][j] = fmaxf(v[b][q][j], 0.f);
-                } else if (p.act == SRMI_ACT_LRELU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] >= 0.f ? v[b][q][j] : v[b][q][j] * 0.2f;
-                }
-            }
-        if (p.res1.ptr) {
-            float rr[NB][2][8];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) load8(p.res1, n, pix, (ct * NB + b) * 32 + 16 * q + 8 * lh, rr[b][q]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] * p.alpha + rr[b][q][j];
-        }
-        if (p.res2.ptr) {
-            float rr[NB][2][8];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) load8(p.res2, n, pix, (ct * NB + b) * 32 + 16 * q + 8 * lh, rr[b][q]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] * p.beta + rr[b][q][j];
-        }
-        if (inside && !tail) {
-            if (p.out.ptr) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int cq = (ct * NB + b) * 32 + 16 * q + 8 * lh;
-                        if (p.ps_r == 1) {
-                            store8(p.out, n, pix, cq, v[b][q]);
-                        } else {
-                            const int ij = cq / p.ps_c, cc = cq - ij * p.ps_c;
-                            const int oy = y * p.ps_r + ij / p.ps_r, ox = x * p.ps_r + ij % p.ps_r;
-                            store8(p.out, n, (long long)oy * ow + ox, cc, v[b][q]);
-                        }
-                    }
-            }
-            if (p.out2.ptr) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) store8(p.out2, n, pix, (ct * NB + b) * 32 + 16 * q + 8 * lh, v[b][q]);
-            }
-        }
-        if (p.chansum) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) csum[b][q][j] += inside ? v[b][q][j] : 0.f;
-        }
-        if (tail && inside && lh == 0 && ct == 0) {
-            float rgb[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                rgb[k] = p.tail_mat[3 * k] * v[0][0][0] + p.tail_mat[3 * k + 1] * v[0][0][1] +
-                         p.tail_mat[3 * k + 2] * v[0][0][2] + p.tail_bias[k];
-            if (p.tail_mode == SRMI_TAIL_F32_NCHW) {
-                float* o = (float*)p.tail_out + (long long)n * 3 * p.h * p.w + pix;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) o[(long long)k * p.h * p.w] = rgb[k];
-            } else {
-                unsigned char* o = (unsigned char*)p.tail_out + ((long long)n * p.h * p.w + pix) * 3;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) o[k] = to_u8(rgb[k], p.tail_lo, p.tail_hi, p.tail_scale, p.tail_round);
-            }
-        }
-    }
-
     STAMP();
-    if (p.chansum) {
-        // deterministic tile sums: lanes -> wave (xor shuffles inside each 32-lane half), waves -> LDS
-        float* red = (float*)smem;  // [4 waves][32*NB]; the pixel patch is no longer needed
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float s = csum[b][q][j];
-#pragma unroll
-                    for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m);
-                    if (lx == 0) red[wave * 32 * NB + b * 32 + 16 * q + 8 * lh + j] = s;
-                }
-        __syncthreads();
-        if (tid < 32 * NB) {
-            const float s = (red[tid] + red[32 * NB + tid]) + (red[2 * 32 * NB + tid] + red[3 * 32 * NB + tid]);
-            const int cq = ct * 32 * NB + tid;
-            if (cq < p.cout_real)
-                p.chansum[((long long)n * (p.tiles_x * p.tiles_y) + tile) * p.cout_real + cq] = s;
-        }
-    }
 #endif
 }
 
 // ---- host launcher --------------------------------------------------------------------------------
 template <int DT, int MB, int NB>
 static int launch(const ConvParams& p, hipStream_t stream) {
-    constexpr size_t lds = ConvGeom<MB, NB>::LDS_BYTES;
+    constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL;
     static bool configured = false;
     if (!configured) {
         SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB>,
@@ -411,9 +518,9 @@ static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
         if (mb == 3) return launch<DT, 3, 1>(p, s);
         return launch<DT, 4, 1>(p, s);
     }
+    // 4 rows x 64 channels per wave does not fit the 256-register budget of two waves per SIMD
     if (mb == 2) return launch<DT, 2, 2>(p, s);
-    if (mb == 3) return launch<DT, 3, 2>(p, s);
-    return launch<DT, 4, 2>(p, s);
+    return launch<DT, 3, 2>(p, s);
 }
 
 static int default_rows_per_wave() { return 2; }
@@ -440,6 +547,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     if (d->cout_tile != 32 && d->cout_tile != 64) SRMI_FAIL("srmi_conv3x3: cout_tile must be 32 or 64");
     const int mb = d->rows_per_wave ? d->rows_per_wave : default_rows_per_wave();
     if (mb < 2 || mb > 4) SRMI_FAIL("srmi_conv3x3: rows_per_wave must be 2, 3 or 4");
+    if (d->cout_tile == 64 && mb == 4) SRMI_FAIL("srmi_conv3x3: rows_per_wave 4 needs cout_tile 32");
     const bool tail = d->tail_mode != SRMI_TAIL_NONE;
     if (tail) {
         if (d->cout != 3 || !d->tail_out) SRMI_FAIL("srmi_conv3x3: an RGB tail needs cout == 3 and tail_out");

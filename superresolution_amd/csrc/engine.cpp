@@ -73,6 +73,8 @@ struct srmi_model {
     float* first_w = nullptr;  // [27][nf]
     float* first_b = nullptr;
     float sub_mat[9], sub_bias[3], add_mat[9], add_bias[3];
+    float core_shift[3] = {0, 0, 0};
+    bool has_core_shift = false;
     std::vector<void*> dev_allocs;
 
     char* ws = nullptr;
@@ -255,7 +257,7 @@ static int pick_rows_per_wave(const srmi_model* m, int h, int w, int cout, int c
     const double rel[5] = {0, 0, 1.0, 0.93, 0.90};
     int best = 2;
     double best_cost = 1e30;
-    for (int mb = 2; mb <= 4; ++mb) {
+    for (int mb = 2; mb <= (cout_tile == 64 ? 3 : 4); ++mb) {
         const long long tiles = (long long)((w + kTileW - 1) / kTileW) * ((h + 4 * mb - 1) / (4 * mb)) *
                                 ((cout + cout_tile - 1) / cout_tile) * ns;
         const long long rounds = (tiles + 255) / 256;
@@ -774,10 +776,22 @@ extern "C" int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t
             memcpy(io.pre_mat, m->sub_mat, sizeof(io.pre_mat));
             memcpy(io.post_mat, m->add_mat, sizeof(io.post_mat));
             for (int i = 0; i < 3; ++i) { io.pre_bias[i] = m->sub_bias[i]; io.post_bias[i] = m->add_bias[i]; }
+        } else if (m->has_core_shift) {
+            for (int i = 0; i < 3; ++i) { io.pre_bias[i] = -m->core_shift[i]; io.post_bias[i] = m->core_shift[i]; }
         }
         io.lo = 0.f; io.hi = 255.f; io.scale = 1.f;
     }
     return forward(m, io, n, h, w, (hipStream_t)hip_stream);
+}
+
+// Core (no-MeanShift) models on the u8 runner path: p - shift before the first conv, + shift after
+// the last (edsr.cpp:36-37,116); full models take the shift from their MeanShift tensors instead.
+extern "C" int srmi_model_set_rgb_shift(srmi_model_t* m, const float* shift) {
+    if (!m || !shift) SRMI_FAIL("srmi_model_set_rgb_shift: null argument");
+    if (m->d.arch == SRMI_ARCH_RRDBNET || m->d.with_meanshift) return 0;
+    for (int i = 0; i < 3; ++i) { m->core_shift[i] = shift[i]; }
+    m->has_core_shift = true;
+    return 0;
 }
 
 extern "C" size_t srmi_model_workspace_bytes(const srmi_model_t* m) { return m ? m->ws_bytes : 0; }

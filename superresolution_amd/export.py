@@ -1,0 +1,58 @@
+"""Weight files for the C runner API (include/edsr.h, rcan.h, realesrgan.h).
+
+The reference runners load a vendor-compiled `.dla` blob (edsr.cpp:126-157); the MI355X runners
+load this container instead: the architecture hyper-parameters plus the state_dict tensors in the
+reference's key layout, float32 little endian ("SRMIW001", see csrc/runners.cpp).
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _desc(model):
+    cfg = model._engine_config()
+    return (cfg["arch"], cfg["scale"], cfg["n_feats"], cfg["n_blocks"], cfg.get("n_groups", 0),
+            cfg.get("grow_ch", 0), cfg.get("reduction", 0), int(cfg.get("with_meanshift", False)),
+            float(cfg.get("res_scale", 1.0)))
+
+
+def save_weights(model, path):
+    """Write `model` (an EDSR / EDSRCore / RCAN / RCANCore / RRDBNet from this package) to `path`."""
+    arch, scale, nf, nb, ng, gc, red, ms, rs = _desc(model)
+    sd = model.state_dict()
+    with open(path, "wb") as f:
+        f.write(b"SRMIW001")
+        f.write(struct.pack("<8i", arch, scale, nf, nb, ng, gc, red, ms))
+        f.write(struct.pack("<f", rs))
+        f.write(struct.pack("<i", len(sd)))
+        for k, v in sd.items():
+            a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
+            name = k.encode()
+            f.write(struct.pack("<i", len(name)))
+            f.write(name)
+            f.write(struct.pack("<i", a.ndim))
+            f.write(struct.pack(f"<{a.ndim}q", *a.shape))
+            f.write(a.tobytes())
+    return path
+
+
+def convert_checkpoint(checkpoint_path, out_path, arch=None, scale=None):
+    """Official checkpoint (.pt/.pth) -> runner weight file.  `arch` defaults to a guess from the
+    file name (edsr / rcan / anything else = Real-ESRGAN)."""
+    from .edsr_model import load_edsr_from_checkpoint
+    from .rcan_model import infer_scale_from_model_name, load_rcan_from_checkpoint
+    from .realesrgan_model import load_realesrgan_from_checkpoint
+    name = checkpoint_path.lower()
+    arch = arch or ("edsr" if "edsr" in name else "rcan" if "rcan" in name else "realesrgan")
+    if arch == "edsr":
+        model = load_edsr_from_checkpoint(checkpoint_path, scale or 4)
+    elif arch == "rcan":
+        model = load_rcan_from_checkpoint(checkpoint_path, scale or infer_scale_from_model_name(checkpoint_path))
+    else:
+        model, _ = load_realesrgan_from_checkpoint(checkpoint_path)
+    return save_weights(model, out_path)

@@ -1,0 +1,212 @@
+"""CPU tests of the host side: module surface (constructor signatures, state_dict layout, loader
+semantics, file-name heuristics), the C ABI's exported symbols, host-side weight packing, and the
+fail-loudly behaviour without a GPU.  No kernel is launched here."""
+import ast
+import ctypes as C
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from superresolution_amd import _lib, edsr_model, rcan_model, realesrgan_model, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    missing = [s for s in _lib.EXPORTS if not hasattr(L, s)]
+    assert not missing, missing
+    # every function the headers declare is in EXPORTS
+    import re
+    declared = set()
+    for hname in ("srmi355.h", "edsr.h", "rcan.h", "realesrgan.h"):
+        text = open(os.path.join(ROOT, "include", hname)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b((?:srmi|edsr|rcan|realesrgan)_[a-z0-9_]+)\s*\(", text))
+    assert declared <= set(_lib.EXPORTS), declared - set(_lib.EXPORTS)
+    assert L.srmi_version().startswith(b"srmi355")
+    assert L.srmi_device_count() >= 0
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    for nm, mod in [("rrdbnet", realesrgan_model.RRDBNet()), ("edsr", edsr_model.EDSR()),
+                    ("rcan", rcan_model.RCAN(scale=4))]:
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(g[nm + "_keys"]), nm
+        assert [repr(tuple(v.shape)) for v in sd.values()] == list(g[nm + "_shapes"]), nm
+
+
+def test_constructor_signatures_match_reference():
+    def names(f):
+        return [p for p in inspect.signature(f).parameters if p not in ("self", "compute_dtype", "trunk_f32", "device")]
+    assert names(realesrgan_model.RRDBNet.__init__) == ["num_in_ch", "num_out_ch", "num_feat", "num_block", "num_grow_ch", "scale"]
+    assert names(edsr_model.EDSR.__init__) == ["n_resblocks", "n_feats", "scale", "rgb_range", "res_scale", "conv"]
+    assert names(rcan_model.RCAN.__init__) == ["scale", "n_resgroups", "n_resblocks", "n_feats", "reduction", "res_scale", "rgb_range"]
+    d = inspect.signature(edsr_model.EDSR.__init__).parameters
+    assert (d["n_resblocks"].default, d["n_feats"].default, d["scale"].default, d["res_scale"].default) == (32, 256, 4, 0.1)
+    with pytest.raises(ValueError, match="Unsupported scale"):
+        realesrgan_model.RRDBNet(scale=3)
+    with pytest.raises(NotImplementedError):
+        edsr_model.EDSR(n_resblocks=1, n_feats=32, scale=5)
+
+
+def test_filename_heuristics_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    for name, ref_type, ref_scale in zip(g["names"], g["infer_model_type"], g["infer_scale"]):
+        assert realesrgan_model.infer_model_type(str(name)) == ast.literal_eval(str(ref_type))
+        assert rcan_model.infer_scale_from_model_name(str(name)) == int(ref_scale)
+    assert edsr_model.get_meanshift_params() == ast.literal_eval(str(g["edsr_meanshift_params"]))
+    assert rcan_model.get_meanshift_params() == ast.literal_eval(str(g["rcan_meanshift_params"]))
+
+
+def test_meanshift_initialisation():
+    m = edsr_model.EDSR(n_resblocks=1, n_feats=32)
+    assert torch.equal(m.sub_mean.weight.view(3, 3), torch.eye(3))
+    assert torch.allclose(m.sub_mean.bias, -255.0 * torch.tensor(synth.RGB_MEAN))
+    assert torch.allclose(m.add_mean.bias, 255.0 * torch.tensor(synth.RGB_MEAN))
+    assert not m.sub_mean.weight.requires_grad
+    r = rcan_model.RCAN(scale=2, n_resgroups=1, n_resblocks=1)
+    assert torch.equal(r.sub_mean.weight.view(3, 3), torch.eye(3))
+
+
+def test_checkpoint_loaders(tmp_path):
+    # Real-ESRGAN: params_ema > params; DataParallel prefix stripped; strict
+    sd = {k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(num_block=6, seed=1).items()}
+    p = str(tmp_path / "RealESRGAN_x4plus_anime_6B.pth")
+    torch.save({"params": {}, "params_ema": {"module." + k: v for k, v in sd.items()}}, p)
+    model, scale = realesrgan_model.load_realesrgan_from_checkpoint(p)
+    assert scale == 4 and model.num_block == 6 and not model.training
+    assert torch.equal(model.state_dict()["body.5.rdb3.conv5.bias"], sd["body.5.rdb3.conv5.bias"])
+    bad = dict(sd)
+    bad.pop("conv_last.bias")
+    torch.save(bad, str(tmp_path / "RealESRGAN_x4plus_anime_6B_bad.pth"))
+    with pytest.raises(RuntimeError):
+        realesrgan_model.load_realesrgan_from_checkpoint(str(tmp_path / "RealESRGAN_x4plus_anime_6B_bad.pth"))
+    # RCAN: 'state_dict' container, strict
+    sd = {k: torch.from_numpy(v) for k, v in synth.rcan_state_dict(scale=2, seed=2).items()}
+    p = str(tmp_path / "RCAN_BIX2.pt")
+    torch.save({"state_dict": sd}, p)
+    m = rcan_model.load_rcan_from_checkpoint(p, rcan_model.infer_scale_from_model_name(p))
+    assert m.scale == 2 and torch.equal(m.state_dict()["tail.0.0.weight"], sd["tail.0.0.weight"])
+    # EDSR: custom load_state_dict semantics (edsr_model.py:126-143)
+    sd = {k: torch.from_numpy(v) for k, v in synth.edsr_state_dict(n_resblocks=2, n_feats=64, scale=4, seed=3).items()}
+    m = edsr_model.EDSR(n_resblocks=2, n_feats=64, scale=2)          # other scale: tail shapes differ
+    m.load_state_dict(sd)                                            # tail mismatches are tolerated ...
+    assert torch.equal(m.state_dict()["body.1.body.2.weight"], sd["body.1.body.2.weight"])
+    wrong = dict(sd)
+    wrong["head.0.weight"] = torch.zeros(8, 3, 3, 3)
+    with pytest.raises(RuntimeError, match="While copying the parameter named head.0.weight"):
+        m.load_state_dict(wrong)                                     # ... others are not
+    extra = dict(sd)
+    extra["foo.weight"] = torch.zeros(1)
+    with pytest.raises(KeyError, match="unexpected key"):
+        m.load_state_dict(extra, strict=True)
+    m.load_state_dict(extra, strict=False)
+    extra2 = dict(sd)
+    extra2["tail.9.weight"] = torch.zeros(1)
+    m.load_state_dict(extra2, strict=True)                           # unexpected tail keys are ignored
+    p = str(tmp_path / "EDSR_x4.pt")
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in synth.edsr_state_dict(n_resblocks=32, n_feats=256, seed=4).items()}}, p)
+    full = edsr_model.load_edsr_from_checkpoint(p, scale=4)
+    assert sum(x.numel() for x in full.parameters()) == 43089947
+
+
+def test_core_models_share_weights():
+    full = rcan_model.RCAN(scale=4, n_resgroups=1, n_resblocks=2)
+    core = rcan_model.create_core_model_from_full(full, 4)
+    assert "sub_mean.weight" not in core.state_dict()
+    assert all(torch.equal(v, full.state_dict()[k]) for k, v in core.state_dict().items())
+    fulle = edsr_model.EDSR(n_resblocks=2, n_feats=32)
+    coree = edsr_model.create_core_model_from_full(fulle, 4)
+    assert len(coree.state_dict()) == len(fulle.state_dict()) - 4
+
+
+def _f16_bits(x):
+    return np.asarray(x, np.float32).astype(np.float16).view(np.uint16)
+
+
+def test_weight_packing_layout_and_rounding():
+    """srmi_pack_conv3x3: f16/bf16 rounding equals numpy / torch round-to-nearest-even, and the
+    image layout is [tile][stage][tap][row][2 swizzled 16-byte chunks]."""
+    L = _lib.lib()
+    cout, cin = 64, 64
+    w = (synth.hash_uniform("pw", (cout, cin, 3, 3), 1) * 3.0).astype(np.float32)
+    w[0, 0, 0, 0] = 65520.0      # rounds to inf in f16
+    w[0, 1, 0, 0] = 5.9e-8       # f16 subnormal range
+    w[0, 2, 0, 0] = 2.0 ** -25   # tie -> 0
+    b = synth.hash_uniform("pb", (cout,), 2)
+    for dt, tile in [(_lib.F16, 64), (_lib.F16, 32), (_lib.BF16, 64), (_lib.F32, 64)]:
+        nb = C.c_int()
+        nbytes = L.srmi_pack_conv3x3_bytes(dt, cout, cin, tile, C.byref(nb))
+        assert nbytes == cout * cin * 9 * (4 if dt == _lib.F32 else 2) and nb.value == cout
+        wp = np.zeros(nbytes, np.uint8)
+        bp = np.zeros(nb.value, np.float32)
+        assert L.srmi_pack_conv3x3(dt, cout, cin, tile, 1, w.ctypes.data, b.ctypes.data, wp.ctypes.data, bp.ctypes.data) == 0
+        assert np.array_equal(bp, b)
+        esz = 4 if dt == _lib.F32 else 2
+        cpb, epc = 64 // esz, 16 // esz
+        nstage = 2 * (cin // cpb)
+        img = wp.reshape(cout // tile, nstage, 9, tile, 2, 16)
+        rng = np.random.default_rng(0)
+        for _ in range(200):
+            o, ci, tap = int(rng.integers(cout)), int(rng.integers(cin)), int(rng.integers(9))
+            if _ < 3:
+                o, ci, tap = 0, _, 0
+            t, row = divmod(o, tile)
+            st = (ci // cpb) * 2 + (ci % cpb) // (2 * epc)
+            c, e = divmod(ci % (2 * epc), epc)
+            slot = c ^ (((tap * tile + row) >> 3) & 1)
+            raw = img[t, st, tap, row, slot, e * esz:(e + 1) * esz].tobytes()
+            v = w[o, ci, tap // 3, tap % 3]
+            if dt == _lib.F32:
+                assert np.frombuffer(raw, np.float32)[0] == v
+            elif dt == _lib.F16:
+                assert np.frombuffer(raw, np.uint16)[0] == _f16_bits(v), (o, ci, tap, v)
+            else:
+                want = torch.tensor([v]).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)[0]
+                assert np.frombuffer(raw, np.uint16)[0] == want
+    # pixel-shuffle packing permutes output channels: packed q = ij*C + c  <-  original c*r*r + ij
+    cout, r = 128, 2
+    w = synth.hash_uniform("pw2", (cout, 32, 3, 3), 3)
+    b = np.arange(cout, dtype=np.float32)
+    nb = C.c_int()
+    nbytes = L.srmi_pack_conv3x3_bytes(_lib.F32, cout, 32, 64, C.byref(nb))
+    wp = np.zeros(nbytes, np.uint8)
+    bp = np.zeros(nb.value, np.float32)
+    assert L.srmi_pack_conv3x3(_lib.F32, cout, 32, 64, r, w.ctypes.data, b.ctypes.data, wp.ctypes.data, bp.ctypes.data) == 0
+    cafter = cout // (r * r)
+    assert all(bp[q] == (q % cafter) * r * r + q // cafter for q in range(cout))
+    # bad shapes fail loudly
+    assert L.srmi_pack_conv3x3_bytes(_lib.F16, 64, 50, 64, None) == 0
+    assert L.srmi_pack_conv3x3(_lib.F16, 64, 50, 64, 1, w.ctypes.data, None, wp.ctypes.data, bp.ctypes.data) == -1
+    assert b"bad shape" in L.srmi_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_forward_without_gpu_fails_loudly():
+    m = realesrgan_model.RRDBNet(num_block=1)
+    with pytest.raises(_lib.SrmiError, match="no HIP device"):
+        m(torch.zeros(1, 3, 8, 8))
+    d = _lib.ModelDesc()
+    d.arch, d.dtype, d.scale, d.n_feats, d.n_blocks, d.grow_ch = _lib.ARCH_RRDBNET, _lib.F16, 4, 64, 1, 32
+    h = C.c_void_p()
+    assert _lib.lib().srmi_model_create(C.byref(d), C.byref(h)) == -1
+
+
+def test_model_create_validates_arguments():
+    L = _lib.lib()
+    d = _lib.ModelDesc()
+    h = C.c_void_p()
+    d.arch, d.dtype, d.scale, d.n_feats, d.n_blocks, d.grow_ch = _lib.ARCH_RRDBNET, _lib.F16, 3, 64, 1, 32
+    assert L.srmi_model_create(C.byref(d), C.byref(h)) == -1
+    assert b"Unsupported scale: 3" in L.srmi_last_error()
+    d.scale, d.n_feats = 4, 50
+    assert L.srmi_model_create(C.byref(d), C.byref(h)) == -1
+    d.arch, d.n_feats, d.scale = _lib.ARCH_EDSR, 64, 5
+    assert L.srmi_model_create(C.byref(d), C.byref(h)) == -1
+    assert b"not supported" in L.srmi_last_error()
+    assert L.srmi_model_create(None, C.byref(h)) == -1

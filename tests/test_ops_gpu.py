@@ -35,7 +35,7 @@ def assert_close(got, ref, rel, what=""):
 
 
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
-@pytest.mark.parametrize("mb", [2, 3, 4])
+@pytest.mark.parametrize("mb", [2, 3])
 def test_conv_64_64_relu(dt, name, tol, mb):
     n, h, w = 2, 33, 47
     x = q(rnd("x", (n, 64, h, w), 1), dt)
@@ -86,10 +86,12 @@ def test_dense_slice_store_lrelu(dt, name, tol):
     dense = ops.Planes.from_nchw(full, dt)
     pc = ops.PackedConv(wt.numpy(), b.numpy(), dt)
     assert pc.cout_tile == 32
-    ops.conv3x3(dense, pc, act=_lib.ACT_LRELU, out=dense, out_c0=96)
-    got = dense.to_nchw().cpu()
-    assert_close(got[:, 96:128], ref, tol, f"slice {name}")
-    assert torch.equal(got[:, :96], full[:, :96]) and torch.equal(got[:, 128:], full[:, 128:])
+    for mb in (2, 3, 4):   # the 32-channel tile supports 2, 3 and 4 rows per wave
+        dense = ops.Planes.from_nchw(full, dt)
+        ops.conv3x3(dense, pc, act=_lib.ACT_LRELU, out=dense, out_c0=96, rows_per_wave=mb)
+        got = dense.to_nchw().cpu()
+        assert_close(got[:, 96:128], ref, tol, f"slice {name} mb={mb}")
+        assert torch.equal(got[:, :96], full[:, :96]) and torch.equal(got[:, 128:], full[:, 128:])
 
 
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
@@ -146,7 +148,7 @@ def test_rgb_tail(dt, name, tol):
 
 
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
-@pytest.mark.parametrize("mb", [2, 4])
+@pytest.mark.parametrize("mb", [2, 3])
 def test_chansum(dt, name, tol, mb):
     n, h, w = 2, 35, 50
     x = q(rnd("x", (n, 64, h, w), 1), dt)

@@ -1,0 +1,132 @@
+"""The reference runners' C API (include/realesrgan.h, edsr.h, rcan.h) on the GPU: same calls as
+realesrgan/mtk/cpp/jni/src/main.cpp:42-109 (init -> inference_ex -> free -> release), checked
+against the oracle's runner pipeline (C pre-processing -> reference forward -> C post-processing)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sr_oracle as O
+from superresolution_amd import _lib, export, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+class RealesrganCtx(C.Structure):
+    _fields_ = [("neuron_executor", C.c_void_p), ("input_width", C.c_int), ("input_height", C.c_int),
+                ("input_channels", C.c_int), ("output_width", C.c_int), ("output_height", C.c_int),
+                ("output_channels", C.c_int), ("scale_factor", C.c_int), ("input_size", C.c_size_t),
+                ("output_size", C.c_size_t), ("initialized", C.c_int)]
+
+
+class MeanshiftCtx(C.Structure):
+    _fields_ = [("neuron_executor", C.c_void_p), ("input_width", C.c_int), ("input_height", C.c_int),
+                ("input_channels", C.c_int), ("output_width", C.c_int), ("output_height", C.c_int),
+                ("output_channels", C.c_int), ("scale_factor", C.c_int), ("rgb_mean", C.c_float * 3),
+                ("rgb_range", C.c_float), ("input_size", C.c_size_t), ("output_size", C.c_size_t),
+                ("initialized", C.c_int)]
+
+
+libc = C.CDLL(None)
+libc.free.argtypes = [C.c_void_p]
+
+
+def _take(ptr, h, w):
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_ubyte)), shape=(h, w, 3)).copy()
+    libc.free(ptr)
+    return a
+
+
+def test_realesrgan_runner(tmp_path):
+    L = _lib.lib()
+    meta = dict(arch="rrdbnet", num_block=2, scale=4, seed=41, input="unit")
+    model, sd = H.build_model(meta, "f16")
+    path = str(tmp_path / "RealESRGAN_x4plus_test.srmi")
+    export.save_weights(model, path)
+    ctx = RealesrganCtx()
+    assert L.realesrgan_init(path.encode(), C.byref(ctx)) == 0
+    assert (ctx.input_width, ctx.input_height, ctx.output_width, ctx.output_height, ctx.scale_factor) == \
+        (510, 339, 2040, 1356, 4) and ctx.initialized == 1
+    # exact-size input
+    img = synth.smooth_image(339, 510, 3)
+    out = C.c_void_p()
+    assert L.realesrgan_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), C.byref(out)) == 0
+    got = _take(out, 1356, 2040)
+    with torch.no_grad():
+        ref = O.post_unit(H.oracle_forward(meta, sd, O.pre_unit(img)), O.ROUND_HALF_UP)[0]
+    d = np.abs(got.astype(int) - ref.astype(int))
+    print(f"runner exact-size: max diff {d.max()} PSNR {O.psnr_u8(got, ref):.2f}")
+    assert d.max() <= 1 and O.psnr_u8(got, ref) >= 50
+    # other size -> bilinear resize first (realesrgan.cpp:278-289)
+    small = synth.smooth_image(100, 150, 4)
+    ow, oh = C.c_int(), C.c_int()
+    assert L.realesrgan_inference_ex(C.byref(ctx), small.ctypes.data_as(C.c_void_p), 150, 100, C.byref(out),
+                                     C.byref(ow), C.byref(oh)) == 0
+    assert (ow.value, oh.value) == (2040, 1356)
+    got = _take(out, 1356, 2040)
+    resized = O.resize_bilinear_u8(small, 510, 339)
+    with torch.no_grad():
+        ref = O.post_unit(H.oracle_forward(meta, sd, O.pre_unit(resized)), O.ROUND_HALF_UP)[0]
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+    # error behaviour (realesrgan.cpp:220-223, 269-272, 197-199)
+    assert L.realesrgan_inference(C.byref(ctx), None, C.byref(out)) == -1
+    assert L.realesrgan_inference_ex(C.byref(ctx), small.ctypes.data_as(C.c_void_p), 150, 100, C.byref(out), None,
+                                     C.byref(oh)) == -1
+    assert L.realesrgan_release(C.byref(ctx)) == 0
+    assert ctx.initialized == 0
+    assert L.realesrgan_release(C.byref(ctx)) == -1
+    assert L.realesrgan_init(b"/nonexistent/file", C.byref(ctx)) == -1
+    assert L.realesrgan_init(None, C.byref(ctx)) == -1
+
+
+@pytest.mark.parametrize("name", ["edsr", "rcan"])
+@pytest.mark.parametrize("core", [False, True])
+def test_meanshift_runners(tmp_path, name, core):
+    """edsr_/rcan_ runners with a full-model file and with a Core-model file (the reference's
+    .dla is the Core model; the runner then applies ctx.rgb_mean * ctx.rgb_range itself)."""
+    L = _lib.lib()
+    from superresolution_amd import edsr_model, rcan_model
+    if name == "edsr":
+        meta = dict(arch="edsr", n_resblocks=2, n_feats=64, scale=4, seed=42, input="range")
+        iw, ih = 256, 256
+    else:
+        meta = dict(arch="rcan", n_resgroups=1, n_resblocks=2, scale=4, seed=43, input="range")
+        iw, ih = 510, 339
+    model, sd = H.build_model(meta, "f16")
+    if core:
+        model = (edsr_model if name == "edsr" else rcan_model).create_core_model_from_full(model, 4)
+    path = str(tmp_path / f"{name}.srmi")
+    export.save_weights(model, path)
+    ctx = MeanshiftCtx()
+    init, infer, infer_ex, release = (getattr(L, f"{name}_{f}") for f in ("init", "inference", "inference_ex", "release"))
+    assert init(path.encode(), C.byref(ctx)) == 0
+    assert (ctx.input_width, ctx.input_height, ctx.scale_factor) == (iw, ih, 4)
+    assert abs(ctx.rgb_mean[0] - 0.4488) < 1e-6 and ctx.rgb_range == 255.0
+    img = synth.smooth_image(ih, iw, 5)
+    out = C.c_void_p()
+    assert infer(C.byref(ctx), img.ctypes.data_as(C.c_void_p), C.byref(out)) == 0
+    got = _take(out, ih * 4, iw * 4)
+    with torch.no_grad():
+        ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(img)), O.ROUND_HALF_UP)[0]
+    d = np.abs(got.astype(int) - ref.astype(int))
+    print(f"{name} runner core={core}: max diff {d.max()} PSNR {O.psnr_u8(got, ref):.2f}")
+    assert d.max() <= 1 and O.psnr_u8(got, ref) >= 50
+    # NULL out_w/out_h are allowed here (edsr.cpp:293-294)
+    small = synth.smooth_image(60, 80, 6)
+    assert infer_ex(C.byref(ctx), small.ctypes.data_as(C.c_void_p), 80, 60, C.byref(out), None, None) == 0
+    libc.free(out)
+    assert release(C.byref(ctx)) == 0
+    assert release(C.byref(ctx)) == 0  # uninitialised context -> 0 (edsr.cpp:185-187)
+
+
+def test_wrong_architecture_file_is_rejected(tmp_path):
+    L = _lib.lib()
+    model, _ = H.build_model(dict(arch="edsr", n_resblocks=1, n_feats=64, scale=4, seed=1, input="range"), "f16")
+    path = str(tmp_path / "edsr.srmi")
+    export.save_weights(model, path)
+    ctx = RealesrganCtx()
+    assert L.realesrgan_init(path.encode(), C.byref(ctx)) == -1
+    assert b"architecture" in L.srmi_last_error()

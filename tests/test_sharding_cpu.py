@@ -1,0 +1,79 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the frame / tile sharding logic with a stand-in
+for the network (nearest x4 upscale, for which halo tiling is exact), plus geometry unit tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from superresolution_amd import sharding, synth
+
+
+def fake_forward(img):  # u8 HWC -> u8 HWC x4 (nearest)
+    return img.repeat_interleave(4, dim=0).repeat_interleave(4, dim=1)
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 9, 64):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                seen += list(sharding.shard_range(n, r, world))
+            assert seen == list(range(n))
+            sizes = [len(sharding.shard_range(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 2, 2)
+
+
+def test_tile_grid_and_stitch():
+    h, w = 67, 101
+    tiles = sharding.tile_grid(h, w, 32, 48, 10)
+    cover = np.zeros((h, w), int)
+    for t in tiles:
+        cover[t.y0:t.y1, t.x0:t.x1] += 1
+        assert t.py0 <= t.y0 and t.py1 >= t.y1 and t.px0 <= t.x0 and t.px1 >= t.x1
+        assert t.py0 == max(t.y0 - 10, 0) and t.px1 == min(t.x1 + 10, w)
+    assert (cover == 1).all()
+    img = torch.from_numpy(synth.random_image(h, w, 1))
+    out = sharding.upscale_tiled(fake_forward, img, 4, 32, 48, 10)
+    assert torch.equal(out, fake_forward(img))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        img = torch.from_numpy(synth.random_image(70, 90, 3))
+        out = sharding.upscale_tiled_sharded(fake_forward, img, 4, 32, 32, 6, rank, world)
+        frames = torch.from_numpy(synth.random_image(16, 20, 4, n=5))
+        own, outs = sharding.upscale_frames_sharded(fake_forward, frames, rank, world)
+        ok = all(torch.equal(o, fake_forward(frames[i])) for i, o in zip(own, outs))
+        if rank == 0:
+            ok = ok and torch.equal(out, fake_forward(img))
+        else:
+            ok = ok and out is None
+        ret[rank] = (bool(ok), list(own))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tile_and_frame_sharding_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] + ret[1][1] == [0, 1, 2, 3, 4]

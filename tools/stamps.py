@@ -12,7 +12,7 @@ from tools.bench_conv import bench
 us, tf = bench(cin, cout, h, w, mb, iters=3)
 torch.cuda.synchronize()
 s = buf.cpu().numpy().reshape(tiles, 40)
-ncb = cin // 32
+ncb = 2 * (cin // 32)  # stages
 nst = 2 + 2 * ncb + 1
 s = s[:, :nst].astype(np.float64)
 t0 = s[:, 0].min()
@@ -25,7 +25,9 @@ print("kernel span (ticks):", (s[:, -1].max() - t0))
 d = np.diff(s, axis=1)
 names = ["prologue(load0+commit+barrier)"]
 for cb in range(ncb):
-    names += [f"cb{cb} compute", f"cb{cb} commit+wait+barrier"]
+    names += [f"stage{cb} compute", f"stage{cb} wait+barrier"]
 names += ["epilogue"]
-for i, nm in enumerate(names):
+rows = list(enumerate(names))
+if len(rows) > 12: rows = rows[:7] + rows[-5:]
+for i, nm in rows:
     print(f"  {nm:34s} p50 {np.median(d[:, i]):8.0f}  p10 {np.percentile(d[:, i],10):8.0f} p90 {np.percentile(d[:, i],90):8.0f}")
