@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--sweep", type=int, default=1, help="frames swept through each layer together")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="engine-internal HIP streams the frames of a step are spread over (srmi_model_set_lanes)")
     ap.add_argument("--streams", type=int, default=1, help="independent frame streams per GPU (each its own engine)")
     ap.add_argument("--trunk-f32", action="store_true",
                     help="keep an extra f32 copy of the residual trunk (default: f16 trunk, which meets the same "
@@ -120,6 +122,7 @@ def main():
         models.append(model)
         engs.append(model.engine())
         engs[-1].set_sweep(args.sweep)
+        engs[-1].set_lanes(args.lanes)
     eng = engs[0]
     scale = eng.scale
     imgs = torch.from_numpy(synth.random_image(h, w, 100 + rank, n=batch)).cuda()
@@ -188,7 +191,8 @@ def main():
                     "official state_dict layout)",
             "config": {"workload": f"{args.model} x{scale} {w}x{h}->{w * scale}x{h * scale}, "
                                    f"{batch} frames per GPU per step, u8 in HBM -> u8 in HBM",
-                       "frames_per_gpu_per_step": batch, "sweep": args.sweep, "streams": args.streams,
+                       "frames_per_gpu_per_step": batch, "sweep": args.sweep, "lanes": args.lanes,
+                       "streams": args.streams,
                        "trunk_f32": args.trunk_f32, "parallelism": f"frame-sharded x{world}, no collective"},
             "ms_per_frame_per_gpu": round(dev_s / (batch * args.steps) * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",

@@ -20,7 +20,8 @@
 //               workgroup, out-of-image lanes carry an offset beyond the buffer descriptor's range
 //               and therefore read zeros (= the convolution's zero padding); nearest-x2
 //               upsampling is a pure address map.
-// Stages are double buffered: stage s+1 is in flight while stage s feeds the MFMAs.
+// Stages form a ring (three deep where LDS allows, else two): up to two stages are in flight
+// behind the one that feeds the MFMAs; counted vmcnt waits and one raw s_barrier per stage.
 // LDS rows are 32 bytes; the 16-byte chunk index is XORed with (row>>3)&1 so that the 16-lane
 // groups of ds_read_b128 touch 16 different bank slots (conflict-free).
 //
@@ -60,7 +61,10 @@ struct ConvGeom {
     static constexpr int B_BYTES = 9 * 32 * NB * 32;       // weight image of one stage
     static constexpr int B_PIECES = B_BYTES / 1024;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // + 32*NB floats of bias behind it
+    // ring of stages: three deep (two stages in flight behind the one being multiplied) where two
+    // workgroups still fit a CU's 160 KiB, else two deep
+    static constexpr int NS = (3 * STAGE_BYTES + 32 * NB * 4 <= 80 * 1024) ? 3 : 2;
+    static constexpr int LDS_BYTES = NS * STAGE_BYTES;     // + 32*NB floats of bias behind it
     static constexpr int LDS_TOTAL = LDS_BYTES + 32 * NB * 4;
 };
 
@@ -301,6 +305,26 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
     }
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 template <int DT, int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
@@ -390,11 +414,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
 #else
 #define STAMP() do {} while (0)
 #endif
+    // LDS-DMA operations this wave issues per stage (its share of the 1-KiB pieces): the count a
+    // counted vmcnt wait must leave outstanding to keep the NEXT stage in flight.
+    int my_pieces = 0;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) my_pieces += (wave + 4 * j < G::A_PIECES) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) my_pieces += (wave + 4 * j < G::B_PIECES) ? 1 : 0;
+    my_pieces = __builtin_amdgcn_readfirstlane(my_pieces);
+
     STAMP();
     issue(0, 0);
     if (tid < 32 * NB) ((float*)(smem + G::LDS_BYTES))[tid] = p.bias[ct * 32 * NB + tid];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (G::NS == 3 && nstage > 1) issue(1, 1);
     STAMP();
 
     // One fragment set = everything the MFMAs of one horizontal tap (dx) read from LDS.  Two sets
@@ -431,9 +463,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
         }
     };
 
+    int cur = 0;  // ring slot of stage s
     for (int s = 0; s < nstage; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < nstage) issue(s + 1, cur ^ 1);
+        // stage s has landed once at most the younger stage's pieces are still outstanding
+        if (G::NS == 3 && s + 1 < nstage) wait_vmcnt_le(my_pieces);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // one barrier per stage: everybody's share of stage s is in LDS, and everybody is done
+        // reading the slot that the next issue overwrites
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP();
+        {
+            const int ahead = G::NS - 1;
+            int slot = cur + ahead;
+            if (slot >= G::NS) slot -= G::NS;
+            if (s + ahead < nstage) issue(s + ahead, slot);
+        }
 
         const char* Ab = smem + cur * G::STAGE_BYTES;
         const char* Bb = Ab + G::A_BYTES + lx * 32;
@@ -459,11 +504,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
         mma_frag(f0, 1);
         __builtin_amdgcn_sched_barrier(0);
         STAMP();
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        STAMP();
+        cur = cur + 1 == G::NS ? 0 : cur + 1;
     }
+    // the epilogue reuses the stage buffers (channel sums) and reads the bias: all waves must be
+    // out of the main loop first
+    __syncthreads();
 
     // ---- epilogue --------------------------------------------------------------------------------
     // One uniform switch selects straight-line code specialised for the tensor types in use; the

@@ -82,6 +82,15 @@ struct srmi_model {
     int sweep = 1;
     int mb_override = 0;
 
+    // Independent sweeps of one call run on `lanes` internal streams that fork from and join the
+    // caller's stream, so that one sweep's launch gaps, prologues and epilogues overlap another's
+    // main loops.  Each lane owns a slice of the workspace.
+    static constexpr int kMaxLanes = 4;
+    int lanes = 2;
+    hipStream_t lane_stream[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr;
+
     int cdt() const { return d.dtype; }
     int tdt() const { return (d.dtype == SRMI_F32 || d.trunk_f32) ? SRMI_F32 : d.dtype; }  // trunk dtype
     bool split_trunk() const { return tdt() != cdt(); }
@@ -561,34 +570,55 @@ static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t st
     Arena probe;
     probe.ns = ns;
     if (run_plan(m, probe, nullptr, &io, h, w)) return -1;
-    if (probe.off > m->ws_bytes) {
+    const int chunks = (n + ns - 1) / ns;
+    const int lanes = chunks < m->lanes ? chunks : m->lanes;
+    const size_t lane_bytes = (probe.off + 255) & ~(size_t)255;
+    if (lane_bytes * lanes > m->ws_bytes) {
         // growing the workspace is the only allocation on the forward path; wait for work that
         // may still use the old buffer first
         SRMI_HIP(hipDeviceSynchronize());
         if (m->ws) SRMI_HIP(hipFree(m->ws));
         m->ws = nullptr;
         m->ws_bytes = 0;
-        SRMI_HIP(hipMalloc((void**)&m->ws, probe.off));
-        m->ws_bytes = probe.off;
+        SRMI_HIP(hipMalloc((void**)&m->ws, lane_bytes * lanes));
+        m->ws_bytes = lane_bytes * lanes;
+    }
+    if (lanes > 1) {
+        if (!m->fork) SRMI_HIP(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
+        for (int l = 0; l < lanes; ++l) {
+            if (!m->lane_stream[l]) SRMI_HIP(hipStreamCreateWithFlags(&m->lane_stream[l], hipStreamNonBlocking));
+            if (!m->lane_done[l]) SRMI_HIP(hipEventCreateWithFlags(&m->lane_done[l], hipEventDisableTiming));
+        }
+        SRMI_HIP(hipEventRecord(m->fork, stream));
+        for (int l = 0; l < lanes; ++l) SRMI_HIP(hipStreamWaitEvent(m->lane_stream[l], m->fork, 0));
     }
     const size_t in_img = io.in_kind == SRMI_IN_U8_NHWC ? (size_t)h * w * 3 : (size_t)h * w * 3 * sizeof(float);
     const size_t hh = (size_t)h * m->d.scale, ww = (size_t)w * m->d.scale;
     const size_t out_img = io.tail_mode == SRMI_TAIL_U8_NHWC ? hh * ww * 3 : hh * ww * 3 * sizeof(float);
     const char* in0 = (const char*)io.in;
     char* out0 = (char*)io.out;
-    for (int i = 0; i < n; i += ns) {
+    int rc = 0;
+    for (int i = 0, chunk = 0; i < n && !rc; i += ns, ++chunk) {
+        const int lane = chunk % lanes;
         Exec ex;
         ex.m = m;
-        ex.stream = stream;
+        ex.stream = lanes > 1 ? m->lane_stream[lane] : stream;
         ex.ns = (n - i) < ns ? (n - i) : ns;
         Arena A;
-        A.base = m->ws;
+        A.base = m->ws + (size_t)lane * lane_bytes;
         A.ns = ns;
         io.in = in0 + (size_t)i * in_img;
         io.out = out0 + (size_t)i * out_img;
-        if (run_plan(m, A, &ex, &io, h, w)) return -1;
+        rc = run_plan(m, A, &ex, &io, h, w);
     }
-    return 0;
+    if (lanes > 1) {
+        // join even after a failed launch so that the caller's stream stays ordered behind the lanes
+        for (int l = 0; l < lanes; ++l) {
+            SRMI_HIP(hipEventRecord(m->lane_done[l], m->lane_stream[l]));
+            SRMI_HIP(hipStreamWaitEvent(stream, m->lane_done[l], 0));
+        }
+    }
+    return rc;
 }
 
 }  // namespace srmi
@@ -641,6 +671,11 @@ extern "C" void srmi_model_destroy(srmi_model_t* m) {
     (void)hipDeviceSynchronize();
     for (void* p : m->dev_allocs) (void)hipFree(p);
     if (m->ws) (void)hipFree(m->ws);
+    for (int l = 0; l < srmi_model::kMaxLanes; ++l) {
+        if (m->lane_done[l]) (void)hipEventDestroy(m->lane_done[l]);
+        if (m->lane_stream[l]) (void)hipStreamDestroy(m->lane_stream[l]);
+    }
+    if (m->fork) (void)hipEventDestroy(m->fork);
     delete m;
 }
 
@@ -799,6 +834,13 @@ extern "C" size_t srmi_model_workspace_bytes(const srmi_model_t* m) { return m ?
 extern "C" int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep) {
     if (!m || images_per_sweep < 1) SRMI_FAIL("srmi_model_set_sweep: bad argument");
     m->sweep = images_per_sweep;
+    return 0;
+}
+
+extern "C" int srmi_model_set_lanes(srmi_model_t* m, int lanes) {
+    if (!m || lanes < 1 || lanes > srmi_model::kMaxLanes)
+        SRMI_FAIL("srmi_model_set_lanes: lanes must be 1..%d", srmi_model::kMaxLanes);
+    m->lanes = lanes;
     return 0;
 }
 

@@ -75,6 +75,10 @@ class Engine:
     def set_sweep(self, images_per_sweep):
         check(lib().srmi_model_set_sweep(self._h, int(images_per_sweep)), "srmi_model_set_sweep")
 
+    def set_lanes(self, lanes):
+        """Internal HIP streams (1..4) the sweeps of one call are spread over; results do not depend on it."""
+        check(lib().srmi_model_set_lanes(self._h, int(lanes)), "srmi_model_set_lanes")
+
     def workspace_bytes(self):
         return int(lib().srmi_model_workspace_bytes(self._h))
 

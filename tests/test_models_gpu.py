@@ -123,6 +123,17 @@ def test_batch_and_sweep_are_bit_identical():
     c = eng.forward_u8(imgs).cpu()
     one = torch.stack([eng.forward_u8(imgs[i]).cpu() for i in range(3)])
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, one)
+    # sweeps spread over 1..4 internal streams, repeated so that a lane's workspace is reused
+    eng.set_sweep(1)
+    imgs7 = torch.from_numpy(synth.random_image(20, 36, 10, n=7)).cuda()
+    eng.set_lanes(1)
+    ref = eng.forward_u8(imgs7).cpu()
+    for lanes in (2, 3, 4):
+        eng.set_lanes(lanes)
+        for _ in range(2):
+            assert torch.equal(eng.forward_u8(imgs7).cpu(), ref), lanes
+    with pytest.raises(Exception):
+        eng.set_lanes(5)
 
 
 def test_core_plus_manual_meanshift_equals_full():
