@@ -16,8 +16,8 @@
  *      runner API (<m>_init / <m>_inference / <m>_inference_ex / <m>_release) on host buffers.
  *
  * Device tensor layout ("planes"): an activation tensor of C channels is stored as
- * [N][C/CPB][H][W][CPB] with CPB = 64 bytes / sizeof(element): 32 channels per plane for
- * f16/bf16, 16 for f32.  A pixel of one plane is therefore always 64 bytes.
+ * [N][C/CPB][H][W][CPB] with CPB = 32 bytes / sizeof(element): 16 channels per plane for
+ * f16/bf16, 8 for f32.  A pixel of one plane is therefore always 32 bytes.
  * Strides in this header are in ELEMENTS of the tensor's own dtype.
  */
 #ifndef SRMI355_H_

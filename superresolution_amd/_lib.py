@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrmi355.so")
+# SRMI_LIB points diagnostic runs at another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("SRMI_LIB") or os.path.join(_HERE, "libsrmi355.so")
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2

@@ -184,7 +184,7 @@ template <typename E>
 __global__ __launch_bounds__(256) void pixel_shuffle_kernel(TView in, TView out, int n_img, int h, int w,
                                                             int c_out, int r) {
     constexpr int EPC = 16 / (int)sizeof(E);      // elements per chunk
-    constexpr int CPB = 64 / (int)sizeof(E);
+    constexpr int CPB = kPixBytes / (int)sizeof(E);
     const int chunks = c_out / EPC;
     const int oh = h * r, ow = w * r;
     const long long total = (long long)n_img * oh * ow * chunks;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(TView in, TView out,
         const int oy = (int)(t % oh);
         const int n = (int)(t / oh);
         const int y = oy / r, x = ox / r, ij = (oy - y * r) * r + (ox - x * r);
-        const char* ibase = in.ptr + (long long)n * in.img_stride_b + ((long long)y * w + x) * 64;
+        const char* ibase = in.ptr + (long long)n * in.img_stride_b + ((long long)y * w + x) * kPixBytes;
         __attribute__((aligned(16))) E v[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -204,25 +204,25 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(TView in, TView out,
         }
         const int co = ck * EPC;
         char* o = out.ptr + (long long)n * out.img_stride_b + (long long)(co / CPB) * out.plane_stride_b +
-                  ((long long)oy * ow + ox) * 64 + (co % CPB) * sizeof(E);
+                  ((long long)oy * ow + ox) * kPixBytes + (co % CPB) * sizeof(E);
         *(u32x4*)o = *(const u32x4*)v;
     }
 }
 
 __global__ __launch_bounds__(256) void nearest_up2_kernel(TView in, TView out, int n_img, int h, int w, int planes) {
     const int oh = 2 * h, ow = 2 * w;
-    const long long total = (long long)n_img * planes * oh * ow * 4;
+    const long long total = (long long)n_img * planes * oh * ow * 2;  // two 16-byte chunks per pixel of a plane
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int ck = (int)(idx & 3);
-        long long t = idx >> 2;
+        const int ck = (int)(idx & 1);
+        long long t = idx >> 1;
         const int ox = (int)(t % ow); t /= ow;
         const int oy = (int)(t % oh); t /= oh;
         const int pl = (int)(t % planes);
         const int n = (int)(t / planes);
         const char* s = in.ptr + (long long)n * in.img_stride_b + (long long)pl * in.plane_stride_b +
-                        ((long long)(oy >> 1) * w + (ox >> 1)) * 64 + ck * 16;
+                        ((long long)(oy >> 1) * w + (ox >> 1)) * kPixBytes + ck * 16;
         char* d = out.ptr + (long long)n * out.img_stride_b + (long long)pl * out.plane_stride_b +
-                  ((long long)oy * ow + ox) * 64 + ck * 16;
+                  ((long long)oy * ow + ox) * kPixBytes + ck * 16;
         *(u32x4*)d = *(const u32x4*)s;
     }
 }
@@ -396,7 +396,7 @@ extern "C" int srmi_nearest_up2(const srmi_tensor_t* in, const srmi_tensor_t* ou
     const int cpb = dtype_cpb(in->dtype);
     if (c <= 0 || c % cpb) SRMI_FAIL("srmi_nearest_up2: c=%d is not a multiple of %d", c, cpb);
     const int planes = c / cpb;
-    const long long total = (long long)n * planes * h * 2 * w * 2 * 4;
+    const long long total = (long long)n * planes * h * 2 * w * 2 * 2;
     hipLaunchKernelGGL(nearest_up2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)hip_stream,
                        to_view(*in), to_view(*out), n, h, w, planes);
     SRMI_HIP(hipGetLastError());

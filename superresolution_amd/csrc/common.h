@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---- device-side tensor view --------------------------------------------------------------------
-// Byte strides; a pixel of one plane is always 64 bytes.
+// Byte strides; a pixel of one plane is always kPixBytes bytes.
 struct TView {
     char* ptr;
     long long img_stride_b;
@@ -34,7 +34,10 @@ struct TView {
 };
 
 static inline int dtype_size(int dt) { return dt == SRMI_F32 ? 4 : 2; }
-static inline int dtype_cpb(int dt) { return dt == SRMI_F32 ? 16 : 32; }  // channels per plane
+// One plane holds kPixBytes bytes of channels per pixel (16 halves or 8 floats): one LDS-DMA stage of the
+// conv kernel reads whole planes, so every fetched cache line is used in full.
+constexpr int kPixBytes = 32;
+static inline int dtype_cpb(int dt) { return dt == SRMI_F32 ? 8 : 16; }  // channels per plane
 
 static inline TView to_view(const srmi_tensor_t& t) {
     TView v;

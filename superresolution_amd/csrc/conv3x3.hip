@@ -13,7 +13,8 @@
 //                writes results with 16-byte accesses.
 //
 // Data movement: the reduction over input channels runs in STAGES of 32 bytes of channels per
-// pixel (16 halves or 8 floats = half a plane).  Per stage both operands are copied
+// pixel (16 halves or 8 floats = one plane of the activation layout, so the fetched cache lines
+// are used in full).  Per stage both operands are copied
 // global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPRs):
 //   weights   : pre-swizzled on the host into exactly the LDS image, a linear copy;
 //   pixels    : (4*MB+2) x 34 halo patch; the per-lane source offset is computed once per
@@ -63,7 +64,10 @@ struct ConvGeom {
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     // ring of stages: three deep (two stages in flight behind the one being multiplied) where two
     // workgroups still fit a CU's 160 KiB, else two deep
-    static constexpr int NS = (3 * STAGE_BYTES + 32 * NB * 4 <= 80 * 1024) ? 3 : 2;
+#ifndef SRMI_RING
+#define SRMI_RING 3
+#endif
+    static constexpr int NS = (SRMI_RING == 3 && 3 * STAGE_BYTES + 32 * NB * 4 <= 80 * 1024) ? 3 : 2;
     static constexpr int LDS_BYTES = NS * STAGE_BYTES;     // + 32*NB floats of bias behind it
     static constexpr int LDS_TOTAL = LDS_BYTES + 32 * NB * 4;
 };
@@ -89,12 +93,12 @@ __device__ __forceinline__ void ld8(const TView& t, int n, long long pix, int c,
     if constexpr (TYPE == kAnyType) {
         load8(t, n, pix, c, v);
     } else if constexpr (TYPE == SRMI_F32) {
-        const char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 64 + (c & 15) * 4;
+        const char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 3) * t.plane_stride_b + pix * 32 + (c & 7) * 4;
         const f32x4 x0 = *(const f32x4*)a, x1 = *(const f32x4*)(a + 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
     } else {
-        const char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 5) * t.plane_stride_b + pix * 64 + (c & 31) * 2;
+        const char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 32 + (c & 15) * 2;
         if constexpr (TYPE == SRMI_F16) {
             const f16x8 x = *(const f16x8*)a;
 #pragma unroll
@@ -112,12 +116,12 @@ __device__ __forceinline__ void st8(const TView& t, int n, long long pix, int c,
     if constexpr (TYPE == kAnyType) {
         store8(t, n, pix, c, v);
     } else if constexpr (TYPE == SRMI_F32) {
-        char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 64 + (c & 15) * 4;
+        char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 3) * t.plane_stride_b + pix * 32 + (c & 7) * 4;
         const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
         *(f32x4*)a = x0;
         *(f32x4*)(a + 16) = x1;
     } else {
-        char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 5) * t.plane_stride_b + pix * 64 + (c & 31) * 2;
+        char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 32 + (c & 15) * 2;
         if constexpr (TYPE == SRMI_F16) {
             f16x8 x;
 #pragma unroll
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
     const int x0 = tx * kTileW, y0 = ty * TH;
     const int ct = blockIdx.y;
     const int n = blockIdx.z;
-    const int nstage = 2 * p.ncb;
+    const int nstage = p.ncb;  // one stage per input plane
 
     // ---- per-lane source offsets of the pixel patch (identical for every stage) ----------------
     // LDS chunk i holds logical chunk c = (i&1) ^ ((pixel>>3)&1) of patch pixel i>>1.
@@ -358,34 +362,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
             int gy = y0 - 1 + rho, gx = x0 - 1 + xi;
             const bool ok = (i < G::NCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
             if (p.in_up2) { gy >>= 1; gx >>= 1; }
-            aoff[j] = ok ? ((unsigned)(gy * srcW + gx) * 64u + (unsigned)c * 16u) : SRMI_OOB_OFFSET;
+            aoff[j] = ok ? ((unsigned)(gy * srcW + gx) * 32u + (unsigned)c * 16u) : SRMI_OOB_OFFSET;
         }
     }
     const char* in_img = p.in.ptr + (long long)n * p.in.img_stride_b;
     const char* w_tile = p.wpk + (size_t)ct * nstage * G::B_BYTES;
     const unsigned plane_bytes = p.in_plane_bytes;
 
-    // stage s = (channel block s>>1, half s&1): 32 bytes of channels per pixel
-    auto issue = [&](int s, int buf) {
-        char* abuf = smem + buf * G::STAGE_BYTES;
-        char* bbuf = abuf + G::A_BYTES;
-        const auto ra = make_rsrc(in_img + (long long)(s >> 1) * p.in.plane_stride_b + (s & 1) * 32,
-                                  plane_bytes - (s & 1) * 32);
-        const auto rb = make_rsrc(w_tile + (size_t)s * G::B_BYTES, G::B_BYTES);
-#pragma unroll
-        for (int j = 0; j < APW; ++j) {
-            const int k = wave + 4 * j;
+    // stage s = input plane s: 32 bytes of channels per pixel.  A wave's share of a
+    // stage is PPW LDS-DMA pieces of 1 KiB: piece q < APW is pixel-patch piece (wave + 4q), the rest
+    // are weight pieces.
+    constexpr int PPW = APW + BPW;
+    auto issue_piece = [&](const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rb, char* abuf, const int q) {
+        if (q < APW) {
+            const int k = wave + 4 * q;
             if (k < G::A_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(abuf + k * 1024),
-                                                         16, aoff[j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int k = wave + 4 * j;
+                                                         16, aoff[q < APW ? q : 0], 0, 0, 0);
+        } else {
+            const int k = wave + 4 * (q - APW);
             if (k < G::B_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(bbuf + k * 1024),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(abuf + G::A_BYTES + k * 1024),
                                                          16, k * 1024 + lane * 16, 0, 0, 0);
         }
+    };
+    auto pixel_rsrc = [&](int s) {
+        return make_rsrc(in_img + (long long)s * p.in.plane_stride_b, plane_bytes);
+    };
+    auto weight_rsrc = [&](int s) { return make_rsrc(w_tile + (size_t)s * G::B_BYTES, G::B_BYTES); };
+    auto issue = [&](int s, int buf) {
+        const auto ra = pixel_rsrc(s);
+        const auto rb = weight_rsrc(s);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) issue_piece(ra, rb, smem + buf * G::STAGE_BYTES, q);
     };
 
     f32x16 acc[MB][NB];
@@ -401,14 +410,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
     const int bm = (lx >> 3) & 1;                  // weight-row swizzle term (row = 32*k + lx)
 
 #ifdef SRMI_STAMPS
+    // diagnostic build: lane 0 of every wave records s_memtime at each phase boundary into
+    // [workgroup][wave][40]; slot 39 holds (XCC_ID << 32) | HW_ID
     unsigned long long* stamp_buf = (unsigned long long*)p.tail_out;
     int stamp_i = 0;
+    const size_t stamp_base = (((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 40;
+    if (stamp_buf && lane == 0) {
+        unsigned hw_, xcc_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        stamp_buf[stamp_base + 39] = ((unsigned long long)xcc_ << 32) | hw_;
+    }
 #define STAMP()                                                                                   \
     do {                                                                                          \
-        if (stamp_buf && tid == 0 && stamp_i < 40) {                                              \
+        if (stamp_buf && lane == 0 && stamp_i < 39) {                                             \
             unsigned long long t_;                                                                \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-            stamp_buf[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 40 + stamp_i++] = t_; \
+            stamp_buf[stamp_base + stamp_i++] = t_;                                               \
         }                                                                                         \
     } while (0)
 #else
@@ -447,8 +465,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
             f.pf[rho] = *(const u32x4*)(Ab + pp * 32 + (((lh ^ (pp >> 3)) & 1) << 4));
         }
     };
-    // part 0: the MFMAs of the first patch row (they only need wf[0] and pf[0]); part 1: the rest
-    auto mma_frag = [&](const Frag& f, const int part) {
+    // part 0: the MFMAs of the first patch row (they only need wf[0] and pf[0]); part 1: the rest.
+    // `after(i)` runs after the i-th multiply step (one 16-byte chunk of channels) of the stage: the main loop issues the next stage's DMA
+    // pieces there, one every few MFMAs, so that their issue cost hides under the matrix pipe.
+    int mfma_i = 0;
+    auto mma_frag = [&](const Frag& f, const int part, auto&& after) {
 #pragma unroll
         for (int rho = 0; rho < MB + 2; ++rho) {
             if ((rho == 0) != (part == 0)) continue;
@@ -457,11 +478,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
                 const int r = rho - dy;
                 if (r >= 0 && r < MB) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) mma_chunk<DT>(acc[r][b], f.wf[dy][b], f.pf[rho]);
+                    for (int b = 0; b < NB; ++b) {
+                        mma_chunk<DT>(acc[r][b], f.wf[dy][b], f.pf[rho]);
+                        after(mfma_i++);
+                    }
                 }
             }
         }
     };
+    constexpr int GAP = (9 * MB * NB) / PPW;  // multiply steps between two DMA pieces
+    static_assert(GAP >= 1, "a stage needs at least as many multiply steps as DMA pieces per wave");
 
     int cur = 0;  // ring slot of stage s
     for (int s = 0; s < nstage; ++s) {
@@ -473,12 +499,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         STAMP();
-        {
-            const int ahead = G::NS - 1;
-            int slot = cur + ahead;
-            if (slot >= G::NS) slot -= G::NS;
-            if (s + ahead < nstage) issue(s + ahead, slot);
-        }
+        const int ahead = G::NS - 1;
+        int slot = cur + ahead;
+        if (slot >= G::NS) slot -= G::NS;
+        const bool more = s + ahead < nstage;
+        const int sn = more ? s + ahead : s;
+        const auto ra = pixel_rsrc(sn);
+        const auto rb = weight_rsrc(sn);
+        char* nbuf = smem + slot * G::STAGE_BYTES;
+#ifdef SRMI_BULK_ISSUE  // diagnostic build: the whole next stage is issued before the multiply steps
+        if (more) issue(sn, slot);
+#endif
+        auto after = [&](const int i) {
+#ifndef SRMI_BULK_ISSUE
+            if (i % GAP == GAP - 1 && i / GAP < PPW) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_piece(ra, rb, nbuf, i / GAP);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        };
 
         const char* Ab = smem + cur * G::STAGE_BYTES;
         const char* Bb = Ab + G::A_BYTES + lx * 32;
@@ -486,22 +526,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
         // (nothing else is outstanding yet); then the next set's ds_reads are issued and run
         // under the remaining MFMAs, so the following step's wait finds them complete.
         Frag f0, f1;
+        mfma_i = 0;
         load_frag(f0, Ab, Bb, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frag(f0, 0);
+        mma_frag(f0, 0, after);
         __builtin_amdgcn_sched_barrier(0);
         load_frag(f1, Ab, Bb, 1);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frag(f0, 1);
+        mma_frag(f0, 1, after);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frag(f1, 0);
+        mma_frag(f1, 0, after);
         __builtin_amdgcn_sched_barrier(0);
         load_frag(f0, Ab, Bb, 2);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frag(f1, 1);
+        mma_frag(f1, 1, after);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frag(f0, 0);
-        mma_frag(f0, 1);
+        mma_frag(f0, 0, after);
+        mma_frag(f0, 1, after);
         __builtin_amdgcn_sched_barrier(0);
         STAMP();
         cur = cur + 1 == G::NS ? 0 : cur + 1;
@@ -607,7 +648,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     if (r > 1 && (d->cout % (r * r * 32) || d->out2.ptr || d->res1.ptr || d->res2.ptr))
         SRMI_FAIL("srmi_conv3x3: pixel-shuffle store needs cout %% (32*r*r) == 0 and no residual/out2");
     if (d->in_up2 && ((d->h | d->w) & 1)) SRMI_FAIL("srmi_conv3x3: in_up2 needs even h and w");
-    if ((long long)d->h * d->w * 64 * r * r >= (1ll << 32)) SRMI_FAIL("srmi_conv3x3: plane larger than 4 GiB");
+    if ((long long)d->h * d->w * kPixBytes * r * r >= (1ll << 32)) SRMI_FAIL("srmi_conv3x3: plane larger than 4 GiB");
 
     ConvParams p;
     p.n = d->n; p.h = d->h; p.w = d->w;
@@ -624,7 +665,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.in = to_view(d->in);
     {
         const long long src_px = d->in_up2 ? (long long)(d->h / 2) * (d->w / 2) : (long long)d->h * d->w;
-        p.in_plane_bytes = (unsigned)(src_px * 64);
+        p.in_plane_bytes = (unsigned)(src_px * kPixBytes);
     }
     p.wpk = (const char*)d->wpk; p.bias = d->bias;
     p.alpha = d->alpha; p.beta = d->beta;

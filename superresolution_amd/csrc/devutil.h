@@ -17,8 +17,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // ---- 4-channel accessors on plane tensors (runtime dtype, wave-uniform branches) -----------------
 __device__ __forceinline__ char* chan_addr(const TView& t, int n, long long pix, int c) {
     char* base = t.ptr + (long long)n * t.img_stride_b;
-    if (t.dtype == SRMI_F32) return base + (long long)(c >> 4) * t.plane_stride_b + pix * 64 + (c & 15) * 4;
-    return base + (long long)(c >> 5) * t.plane_stride_b + pix * 64 + (c & 31) * 2;
+    if (t.dtype == SRMI_F32) return base + (long long)(c >> 3) * t.plane_stride_b + pix * 32 + (c & 7) * 4;
+    return base + (long long)(c >> 4) * t.plane_stride_b + pix * 32 + (c & 15) * 2;
 }
 
 __device__ __forceinline__ void load4(const TView& t, int n, long long pix, int c, float (&v)[4]) {

@@ -236,7 +236,7 @@ struct Arena {
         b.dtype = dtype; b.c = c; b.h = h; b.w = w;
         const size_t planes = (size_t)(c + dtype_cpb(dtype) - 1) / dtype_cpb(dtype);
         b.ptr = base ? base + off : nullptr;
-        off += ((size_t)ns * planes * h * w * 64 + 255) & ~(size_t)255;
+        off += ((size_t)ns * planes * h * w * kPixBytes + 255) & ~(size_t)255;
         return b;
     }
     float* take_floats(size_t n) {

@@ -70,7 +70,7 @@ extern "C" size_t srmi_pack_conv3x3_bytes(int dtype, int cout, int cin, int cout
     if (cin <= 0 || cin % cpb || cout <= 0) return 0;
     const int ntile = (cout + cout_tile - 1) / cout_tile;
     if (bias_floats) *bias_floats = ntile * cout_tile;
-    return (size_t)ntile * (cin / cpb) * 9 * cout_tile * 64;
+    return (size_t)ntile * (cin / cpb) * 9 * cout_tile * kPixBytes;
 }
 
 extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, int ps_r,
@@ -83,7 +83,7 @@ extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, in
     const int r = ps_r <= 1 ? 1 : ps_r;
     if (r > 1 && cout % (r * r * 32)) SRMI_FAIL("srmi_pack_conv3x3: cout=%d incompatible with pixel shuffle %d", cout, r);
     const int cpb = dtype_cpb(dtype), esz = dtype_size(dtype), epc = 16 / esz;  // elements per chunk
-    const int nstage = 2 * (cin / cpb), ntile = nbias / cout_tile;
+    const int nstage = cin / cpb, ntile = nbias / cout_tile;  // one stage per input plane
     char* out = (char*)wpk_out;
     for (int t = 0; t < ntile; ++t)
         for (int st = 0; st < nstage; ++st)
@@ -95,7 +95,7 @@ extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, in
                     for (int c = 0; c < 2; ++c) {
                         char* dst = dst_row + ((c ^ ((img_row >> 3) & 1)) << 4);
                         for (int e = 0; e < epc; ++e) {
-                            const int ci = (st >> 1) * cpb + ((st & 1) * 2 + c) * epc + e;
+                            const int ci = st * cpb + c * epc + e;
                             const float v = o < 0 ? 0.f : w[((size_t)o * cin + ci) * 9 + tap];
                             if (dtype == SRMI_F32) {
                                 memcpy(dst + 4 * e, &v, 4);

@@ -1,7 +1,7 @@
 """Operator-level Python surface over the C ABI (one HIP kernel launch per call).
 
 `Planes` wraps a device buffer in the library's plane layout [N][C/CPB][H][W][CPB]
-(CPB = 32 for f16/bf16, 16 for f32).  The functions mirror the torch ops the reference modules
+(CPB = 16 for f16/bf16, 8 for f32: 32 bytes per pixel per plane).  The functions mirror the torch ops the reference modules
 call; they exist for tests, interop and experimentation — whole networks run through
 `srmi_model_*` (see engine.py) so that a forward pass is a single ctypes call.
 """
@@ -22,8 +22,11 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+PIX_BYTES = 32  # bytes of channels per pixel in one plane
+
+
 def cpb(dtype):
-    return 16 if dtype == F32 else 32
+    return 8 if dtype == F32 else 16
 
 
 class Planes:
@@ -40,9 +43,9 @@ class Planes:
         assert c0 % cpb(self.dtype) == 0
         t = Tensor()
         es = self.buf.element_size()
-        t.ptr = self.buf.data_ptr() + (c0 // cpb(self.dtype)) * self.h * self.w * 64
-        t.img_stride = self.planes * self.h * self.w * 64 // es
-        t.plane_stride = self.h * self.w * 64 // es
+        t.ptr = self.buf.data_ptr() + (c0 // cpb(self.dtype)) * self.h * self.w * PIX_BYTES
+        t.img_stride = self.planes * self.h * self.w * PIX_BYTES // es
+        t.plane_stride = self.h * self.w * PIX_BYTES // es
         t.dtype = self.dtype
         return t
 

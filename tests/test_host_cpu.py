@@ -148,8 +148,8 @@ def test_weight_packing_layout_and_rounding():
         assert L.srmi_pack_conv3x3(dt, cout, cin, tile, 1, w.ctypes.data, b.ctypes.data, wp.ctypes.data, bp.ctypes.data) == 0
         assert np.array_equal(bp, b)
         esz = 4 if dt == _lib.F32 else 2
-        cpb, epc = 64 // esz, 16 // esz
-        nstage = 2 * (cin // cpb)
+        cpb, epc = 32 // esz, 16 // esz
+        nstage = cin // cpb
         img = wp.reshape(cout // tile, nstage, 9, tile, 2, 16)
         rng = np.random.default_rng(0)
         for _ in range(200):
@@ -157,8 +157,8 @@ def test_weight_packing_layout_and_rounding():
             if _ < 3:
                 o, ci, tap = 0, _, 0
             t, row = divmod(o, tile)
-            st = (ci // cpb) * 2 + (ci % cpb) // (2 * epc)
-            c, e = divmod(ci % (2 * epc), epc)
+            st = ci // cpb
+            c, e = divmod(ci % cpb, epc)
             slot = c ^ (((tap * tile + row) >> 3) & 1)
             raw = img[t, st, tap, row, slot, e * esz:(e + 1) * esz].tobytes()
             v = w[o, ci, tap // 3, tap % 3]
