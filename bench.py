@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--sweep", type=int, default=1, help="frames swept through each layer together")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="engine-internal HIP streams the frames of a step are spread over (srmi_model_set_lanes)")
     ap.add_argument("--streams", type=int, default=1, help="independent frame streams per GPU (each its own engine)")
     ap.add_argument("--trunk-f32", action="store_true",
@@ -109,7 +109,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # workload: the configuration BASELINE.json's metric is quoted on
-    defaults = {"rrdbnet": (339, 510, 8), "rcan": (339, 510, 8), "edsr": (256, 256, 32)}
+    defaults = {"rrdbnet": (339, 510, 12), "rcan": (339, 510, 12), "edsr": (256, 256, 36)}
     h, w, batch = defaults[args.model]
     h = args.height or h
     w = args.width or w

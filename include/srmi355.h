@@ -247,7 +247,7 @@ size_t srmi_model_workspace_bytes(const srmi_model_t* m);
 /* Images a forward call sweeps through each layer together (default 1: one image per
  * layer sweep keeps its activations in the 256 MiB Infinity Cache). */
 int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep);
-/* Internal HIP streams (1..4, default 2) over which the sweeps of one forward call are spread.
+/* Internal HIP streams (1..4, default 3) over which the sweeps of one forward call are spread.
  * The lanes fork from and join the caller's stream through events, so a call is ordered on the
  * caller's stream exactly as with one lane; a call with a single sweep uses the caller's stream
  * directly.  Images are independent (realesrgan_model.py:96-123 has no cross-image op), so the

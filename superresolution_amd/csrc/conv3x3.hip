@@ -21,8 +21,9 @@
 //               workgroup, out-of-image lanes carry an offset beyond the buffer descriptor's range
 //               and therefore read zeros (= the convolution's zero padding); nearest-x2
 //               upsampling is a pure address map.
-// Stages form a ring (three deep where LDS allows, else two): up to two stages are in flight
-// behind the one that feeds the MFMAs; counted vmcnt waits and one raw s_barrier per stage.
+// Stages form a ring of SRMI_RING slots (2: with the 12-row tile a workgroup then needs under 53 KiB
+// and three fit a CU, which beats a deeper ring at two per CU); the next stage's pieces are issued
+// between the multiply steps of the current one, counted vmcnt waits and one raw s_barrier per stage.
 // LDS rows are 32 bytes; the 16-byte chunk index is XORed with (row>>3)&1 so that the 16-lane
 // groups of ds_read_b128 touch 16 different bank slots (conflict-free).
 //
@@ -65,7 +66,7 @@ struct ConvGeom {
     // ring of stages: three deep (two stages in flight behind the one being multiplied) where two
     // workgroups still fit a CU's 160 KiB, else two deep
 #ifndef SRMI_RING
-#define SRMI_RING 3
+#define SRMI_RING 2
 #endif
     static constexpr int NS = (SRMI_RING == 3 && 3 * STAGE_BYTES + 32 * NB * 4 <= 80 * 1024) ? 3 : 2;
     static constexpr int LDS_BYTES = NS * STAGE_BYTES;     // + 32*NB floats of bias behind it
@@ -341,11 +342,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
+    // Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2) in linear
+    // launch order.  Re-number them so that one XCD gets a contiguous run of the order
+    // (output-channel tile fastest, then spatial tile, then image): neighbouring spatial tiles share
+    // halo rows and the output-channel tiles of one spatial tile share the whole pixel patch in L2.
+#ifndef SRMI_NO_XCD_MAP
+    int tile, ct, n;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned total = gx * gy * gridDim.z;
+        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned xcd = lin & 7u, j = lin >> 3;
+        const unsigned q = total >> 3, r = total & 7u;
+        unsigned id = xcd * q + (xcd < r ? xcd : r) + j;
+        ct = (int)(id % gy); id /= gy;
+        tile = (int)(id % gx);
+        n = (int)(id / gx);
+    }
+#else
+    const int tile = blockIdx.x, ct = blockIdx.y, n = blockIdx.z;
+#endif
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int x0 = tx * kTileW, y0 = ty * TH;
-    const int ct = blockIdx.y;
-    const int n = blockIdx.z;
     const int nstage = p.ncb;  // one stage per input plane
 
     // ---- per-lane source offsets of the pixel patch (identical for every stage) ----------------

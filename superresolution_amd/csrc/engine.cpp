@@ -86,7 +86,7 @@ struct srmi_model {
     // caller's stream, so that one sweep's launch gaps, prologues and epilogues overlap another's
     // main loops.  Each lane owns a slice of the workspace.
     static constexpr int kMaxLanes = 4;
-    int lanes = 2;
+    int lanes = 3;
     hipStream_t lane_stream[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
