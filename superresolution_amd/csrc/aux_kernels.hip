@@ -9,7 +9,7 @@
 namespace srmi {
 
 // ------------------------------------------------------------------------------------------------
-// First layer (cin = 3): one thread = one pixel x 4 output channels.
+// First layer (cin = 3): one thread = one pixel x 16 output channels.
 // ------------------------------------------------------------------------------------------------
 struct FirstParams {
     int n, h, w, cout, in_kind;
@@ -29,25 +29,25 @@ __device__ __forceinline__ float pre_affine(const float* m, float b, const float
 }
 
 __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
-    const int groups = p.cout >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)p.n * p.h * p.w * groups;
-    if (idx >= total) return;
-    const int cg = (int)(idx % groups);
-    long long pixn = idx / groups;
-    const int x = (int)(pixn % p.w);
-    pixn /= p.w;
-    const int y = (int)(pixn % p.h);
-    const int n = (int)(pixn / p.h);
+    // one thread = one pixel x 16 output channels (one half plane = 32 bytes of halves).  The channel
+    // group is uniform over the workgroup, so the weights come through scalar loads; the 27 inputs
+    // of the pixel are converted once and reused for the 16 outputs.
     const long long hw = (long long)p.h * p.w;
+    const long long pixn = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pixn >= (long long)p.n * hw) return;
+    const int cg = blockIdx.y;
+    const int n = (int)(pixn / hw);
+    const long long pix = pixn - (long long)n * hw;
+    const int y = (int)(pix / p.w), x = (int)(pix - (long long)y * p.w);
 
-    f32x4 acc = *(const f32x4*)(p.bias + cg * 4);
+    float v[27];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int yy = y + ky - 1, xx = x + kx - 1;
-            float v[3] = {0.f, 0.f, 0.f};
+            float* vt = v + (ky * 3 + kx) * 3;
+            vt[0] = vt[1] = vt[2] = 0.f;
             if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
                 float raw[3];
                 if (p.in_kind == SRMI_IN_U8_NHWC) {
@@ -58,80 +58,110 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
                     raw[0] = s[0]; raw[1] = s[hw]; raw[2] = s[2 * hw];
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) v[c] = pre_affine(p.pre_mat + 3 * c, p.pre_bias[c], raw);
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const f32x4 wv = *(const f32x4*)(p.wgt + (long long)((ky * 3 + kx) * 3 + c) * p.cout + cg * 4);
-                acc += wv * v[c];
+                for (int c = 0; c < 3; ++c) vt[c] = pre_affine(p.pre_mat + 3 * c, p.pre_bias[c], raw);
             }
         }
     }
-    const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-    const long long pix = (long long)y * p.w + x;
-    if (p.out.ptr) store4(p.out, n, pix, cg * 4, o);
-    if (p.out2.ptr) store4(p.out2, n, pix, cg * 4, o);
+    float acc[16];
+    const float* bias = p.bias + cg * 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[j];
+    const float* wg = p.wgt + cg * 16;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] += wg[(long long)t * p.cout + j] * v[t];
+    }
+    const float o0[8] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]};
+    const float o1[8] = {acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]};
+    if (p.out.ptr) { store8(p.out, n, pix, cg * 16, o0); store8(p.out, n, pix, cg * 16 + 8, o1); }
+    if (p.out2.ptr) { store8(p.out2, n, pix, cg * 16, o0); store8(p.out2, n, pix, cg * 16 + 8, o1); }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Channel attention
 // ------------------------------------------------------------------------------------------------
 // One workgroup per image: finish the pooling (fixed summation order -> bitwise reproducible),
-// then the squeeze / excite 1x1 convolutions and the sigmoid.
-__global__ __launch_bounds__(256) void ca_scale_kernel(const float* chansum, int tiles, int c, int cr,
-                                                       float inv_hw, const float* w1, const float* b1,
-                                                       const float* w2, const float* b2, float* scale) {
-    extern __shared__ float sh[];  // [4][c] partials, [c] mean, [cr] z
+// then the squeeze / excite 1x1 convolutions and the sigmoid.  The tile partials are summed in
+// kCaParts interleaved groups per channel with sixteen independent loads in flight per thread:
+// the kernel's time is the latency of that chain of global loads.
+constexpr int kCaParts = 16;
+constexpr int kCaThreads = 1024;
+__global__ __launch_bounds__(kCaThreads) void ca_scale_kernel(const float* chansum, int tiles, int c, int cr,
+                                                              float inv_hw, const float* w1, const float* b1,
+                                                              const float* w2, const float* b2, float* scale) {
+    extern __shared__ float sh[];  // [kCaParts][c] partials, [c] mean, [cr] z
     float* part = sh;
-    float* mean = sh + 4 * c;
+    float* mean = sh + kCaParts * c;
     float* z = mean + c;
     const int n = blockIdx.x;
     const float* src = chansum + (long long)n * tiles * c;
-    for (int i = threadIdx.x; i < 4 * c; i += 256) {
+    for (int i = threadIdx.x; i < kCaParts * c; i += kCaThreads) {
         const int ch = i % c, q = i / c;
         float s = 0.f;
-        for (int t = q; t < tiles; t += 4) s += src[(long long)t * c + ch];
+        for (int t = q; t < tiles; t += 16 * kCaParts) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int tt = t + u * kCaParts;
+                v[u] = tt < tiles ? src[(long long)tt * c + ch] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
         part[q * c + ch] = s;
     }
     __syncthreads();
-    for (int ch = threadIdx.x; ch < c; ch += 256)
-        mean[ch] = ((part[ch] + part[c + ch]) + (part[2 * c + ch] + part[3 * c + ch])) * inv_hw;
+    for (int ch = threadIdx.x; ch < c; ch += kCaThreads) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < kCaParts; ++q) s += part[q * c + ch];
+        mean[ch] = s * inv_hw;
+    }
     __syncthreads();
-    for (int j = threadIdx.x; j < cr; j += 256) {
+    for (int j = threadIdx.x; j < cr; j += kCaThreads) {
         float s = b1[j];
         for (int ch = 0; ch < c; ++ch) s += w1[j * c + ch] * mean[ch];
         z[j] = fmaxf(s, 0.f);
     }
     __syncthreads();
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
+    for (int ch = threadIdx.x; ch < c; ch += kCaThreads) {
         float s = b2[ch];
         for (int j = 0; j < cr; ++j) s += w2[ch * cr + j] * z[j];
         scale[(long long)n * c + ch] = 1.f / (1.f + expf(-s));
     }
 }
 
-// out = x + res_scale * (y * s[c]); one thread = one pixel x 8 channels (two 4-channel groups).
+// out = x + res_scale * (y * s[c]); one thread = one pixel x 8 channels (16-byte accesses on half
+// tensors).  Consecutive threads walk the pixels of one plane half, so a wave reads and writes
+// contiguous runs.
 __global__ __launch_bounds__(256) void ca_apply_kernel(TView y, TView x, const float* scale, float res_scale,
                                                        int n_img, long long hw, int c, TView out, TView out2) {
     const int groups = c >> 3;
     const long long total = (long long)n_img * hw * groups;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int g = (int)(idx % groups);
-        const long long pn = idx / groups;
-        const long long pix = pn % hw;
-        const int n = (int)(pn / hw);
+        // index order: (n, group pair, pixel, group within the pair): the two 8-channel groups of a
+        // 16-channel half plane sit next to each other in memory
+        const int sub = (int)(idx & 1);
+        long long t = idx >> 1;
+        const long long pix = t % hw;
+        t /= hw;
+        const int pairs = groups >> 1;
+        const int g = (int)(t % pairs) * 2 + sub;
+        const int n = (int)(t / pairs);
+        const int ch = g * 8;
+        float yv[8], xv[8], o[8];
+        load8(y, n, pix, ch, yv);
+        load8(x, n, pix, ch, xv);
+        const f32x4 s0 = *(const f32x4*)(scale + (long long)n * c + ch);
+        const f32x4 s1 = *(const f32x4*)(scale + (long long)n * c + ch + 4);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int ch = g * 8 + half * 4;
-            float yv[4], xv[4], o[4];
-            load4(y, n, pix, ch, yv);
-            load4(x, n, pix, ch, xv);
-            const f32x4 s = *(const f32x4*)(scale + (long long)n * c + ch);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (yv[j] * s[j]) * res_scale + xv[j];
-            if (out.ptr) store4(out, n, pix, ch, o);
-            if (out2.ptr) store4(out2, n, pix, ch, o);
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (yv[j] * s0[j]) * res_scale + xv[j];
+            o[4 + j] = (yv[4 + j] * s1[j]) * res_scale + xv[4 + j];
         }
+        if (out.ptr) store8(out, n, pix, ch, o);
+        if (out2.ptr) store8(out2, n, pix, ch, o);
     }
 }
 
@@ -324,9 +354,10 @@ extern "C" int srmi_conv_first(const srmi_conv_first_desc_t* d, void* hip_stream
     for (int i = 0; i < 3; ++i) p.pre_bias[i] = d->pre_bias[i];
     p.wgt = d->w_kcio; p.bias = d->bias;
     p.out = to_view(d->out); p.out2 = to_view(d->out2);
-    const long long total = (long long)d->n * d->h * d->w * (d->cout / 4);
+    const long long total = (long long)d->n * d->h * d->w;
     if ((total + 255) / 256 > 0x7fffffffll) SRMI_FAIL("srmi_conv_first: problem too large");
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, p);
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)(d->cout / 16)), dim3(256), 0,
+                       (hipStream_t)hip_stream, p);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
@@ -335,9 +366,9 @@ extern "C" int srmi_ca_scale(const float* chansum, int n, int tiles, int c, int 
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              float* scale, void* hip_stream) {
     if (!chansum || !w1 || !b1 || !w2 || !b2 || !scale) SRMI_FAIL("srmi_ca_scale: null pointer");
-    if (n <= 0 || tiles <= 0 || c <= 0 || cr <= 0 || hw <= 0 || c > 4096) SRMI_FAIL("srmi_ca_scale: bad shape");
-    const size_t lds = (size_t)(5 * c + cr) * sizeof(float);
-    hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(256), lds, (hipStream_t)hip_stream, chansum, tiles, c, cr,
+    if (n <= 0 || tiles <= 0 || c <= 0 || cr <= 0 || hw <= 0 || c > 512) SRMI_FAIL("srmi_ca_scale: bad shape");
+    const size_t lds = (size_t)((kCaParts + 1) * c + cr) * sizeof(float);
+    hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(kCaThreads), lds, (hipStream_t)hip_stream, chansum, tiles, c, cr,
                        1.0f / (float)hw, w1, b1, w2, b2, scale);
     SRMI_HIP(hipGetLastError());
     return 0;
@@ -347,7 +378,7 @@ extern "C" int srmi_ca_apply(const srmi_tensor_t* y, const srmi_tensor_t* x, con
                              float res_scale, int n, int h, int w, int c,
                              const srmi_tensor_t* out, const srmi_tensor_t* out2, void* hip_stream) {
     if (!y || !x || !y->ptr || !x->ptr || !scale || !out) SRMI_FAIL("srmi_ca_apply: null pointer");
-    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 32) SRMI_FAIL("srmi_ca_apply: bad shape");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 16) SRMI_FAIL("srmi_ca_apply: bad shape (c must be a multiple of 16)");
     TView o2;
     o2.ptr = nullptr; o2.img_stride_b = o2.plane_stride_b = 0; o2.dtype = 0; o2.pad = 0;
     if (out2) o2 = to_view(*out2);

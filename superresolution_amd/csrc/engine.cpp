@@ -199,7 +199,12 @@ static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
     ConvW cw;
     cw.cout = (int)w.shape[0];
     cw.cin = (int)w.shape[1];
-    cw.cout_tile = cw.cout <= 32 ? 32 : 64;
+    // 32-wide tiles keep a workgroup under 168 registers and 53 KiB of LDS, so three fit a CU.  In
+    // RRDBNet, where four of five convs of a dense block have 32 outputs anyway, that also pays for
+    // the 64-output convs; EDSR and RCAN (64/256 outputs throughout) run faster on 64-wide tiles,
+    // which fetch the pixel patch once per 64 outputs.
+    cw.cout_tile = (cw.cout <= 32 || m->d.arch == SRMI_ARCH_RRDBNET) ? 32 : 64;
+    if (getenv("SRMI_COUT_TILE")) cw.cout_tile = atoi(getenv("SRMI_COUT_TILE")) == 32 || cw.cout <= 32 ? 32 : 64;  // diagnostic
     cw.ps_r = ps_r;
     int nbias = 0;
     const size_t bytes = srmi_pack_conv3x3_bytes(m->cdt(), cw.cout, cw.cin, cw.cout_tile, &nbias);
@@ -260,22 +265,12 @@ static srmi_tensor_t tv(const Buf& b, int c0 = 0) {
 }
 
 static int pick_rows_per_wave(const srmi_model* m, int h, int w, int cout, int cout_tile, int ns) {
+    (void)w; (void)cout; (void)cout_tile; (void)ns;
     if (m->mb_override) return m->mb_override;
-    // estimated time ~ (rounds of 256 workgroups) x (rows per workgroup) x (per-row cost, lower for
-    // taller wave tiles because weight fragments and LDS pixel rows are reused more)
-    const double rel[5] = {0, 0, 1.0, 0.93, 0.90};
-    int best = 2;
-    double best_cost = 1e30;
-    for (int mb = 2; mb <= (cout_tile == 64 ? 3 : 4); ++mb) {
-        const long long tiles = (long long)((w + kTileW - 1) / kTileW) * ((h + 4 * mb - 1) / (4 * mb)) *
-                                ((cout + cout_tile - 1) / cout_tile) * ns;
-        const long long rounds = (tiles + 255) / 256;
-        // large grids: fractional rounds matter less; blend towards the smooth estimate
-        const double eff_rounds = tiles >= 256 * 8 ? (double)tiles / 256.0 : (double)rounds;
-        const double cost = eff_rounds * 4 * mb * rel[mb];
-        if (cost < best_cost) { best_cost = cost; best = mb; }
-    }
-    return best;
+    // Three rows per wave (12-row tiles) is the fastest variant on every layer of the three networks
+    // when kernels of several lanes share the CUs; only images shorter than one such tile use the
+    // 8-row tile.
+    return h <= 8 ? 2 : 3;
 }
 
 struct Exec {
