@@ -8,11 +8,16 @@ frames -> 2040x1356 u8 frames, one process per GPU, no collective on the data pa
 
 A step = one forward pass of the network over `--batch` synthetic frames per GPU (weak scaling:
 per-GPU work is fixed).  Inputs are resident in HBM before the timed region; outputs stay in HBM.
-Rank 0 prints ONE JSON line.  `roofline` prices the convolution kernels (>99.9 % of the step)
+Rank 0 prints ONE JSON line.  `roofline` prices the convolution kernel (>99 % of the step)
 against the dense f16/bf16 MFMA peak with ALGORITHMIC FLOPs (2*Cin*Cout*9 per output pixel,
 no halo or padding work counted) over the device time of the timed region measured with HIP
-events on the launch stream.  `cpu_baseline` times the CPU oracle (a port of the reference
-PyTorch forward) on a bounded sample on the host cores.
+events on the launch stream.  The engine runs the frames of a step on several internal streams
+("lanes"), so launches overlap: `achieved` is the whole timed region's rate, and `serial` repeats
+a short pass with one lane, where launches run back to back and the average launch duration is
+the one a `rocprofv3 --kernel-trace --stats` run of `bench.py --lanes 1` reports.  `traffic` is
+the L2<->fabric bytes per launch from the PMC passes kept under profiles/ (null when absent).
+`cpu_baseline` times the CPU oracle (a port of the reference PyTorch forward) on a bounded
+sample on the host cores.
 """
 import argparse
 import json
@@ -72,6 +77,31 @@ def cpu_baseline(arch, sd, h, w, threads):
     t = sorted(ts)[1]
     mpix = out.shape[1] * out.shape[2] / 1e6
     return mpix / t, f"1 frame {sw}x{sh} (quarter-area crop of the bench frame), median of 3, {t:.2f} s/frame"
+
+
+def conv_launches_per_frame(model):
+    """conv3x3 kernel launches of one forward (the first 3-channel layer runs in its own small kernel)."""
+    from superresolution_amd import EDSR, RCAN
+    eng = model.engine()
+    up = {2: 1, 3: 1, 4: 2, 8: 3}[eng.scale]
+    if isinstance(model, EDSR):
+        return 2 * model.n_resblocks + 1 + up + 1
+    if isinstance(model, RCAN):
+        return model.n_resgroups * (2 * model.n_resblocks + 1) + 1 + up + 1
+    return 15 * model.num_block + 1 + (2 if eng.scale == 4 else 1) + 2
+
+
+def pmc_traffic(arch, dtype):
+    """Bytes per conv launch between L2 and the fabric (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) from the committed
+    PMC passes of this workload, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        rec = rec.get(f"{arch}:{dtype}")
+        return rec and rec["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def main():
@@ -168,10 +198,26 @@ def main():
         wall, dev_s = float(t[0]), float(t[1])
     torch.cuda.synchronize()
 
+    # serial pass for the per-launch roofline figure: one lane, launches back to back
+    serial = None
+    if rank == 0 and args.streams == 1:
+        eng.set_lanes(1)
+        eng.forward_u8(imgs[:2], _lib.ROUND_HALF_UP, out=out[:2])
+        torch.cuda.synchronize()
+        nser = min(batch, 4)
+        sv0, sv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sv0.record()
+        eng.forward_u8(imgs[:nser], _lib.ROUND_HALF_UP, out=out[:nser])
+        sv1.record()
+        torch.cuda.synchronize()
+        serial = sv0.elapsed_time(sv1) / 1e3 / nser  # seconds per frame
+        eng.set_lanes(args.lanes)
+
     if rank == 0:
         frames = batch * args.steps * world
         out_mpix = frames * (h * scale) * (w * scale) / 1e6
         flops_frame = eng.flops(h, w)
+        launches = conv_launches_per_frame(models[0])
         achieved = flops_frame * batch * args.steps / dev_s / 1e12  # per GPU
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         rec = {
@@ -196,10 +242,18 @@ def main():
                        "trunk_f32": args.trunk_f32, "parallelism": f"frame-sharded x{world}, no collective"},
             "ms_per_frame_per_gpu": round(dev_s / (batch * args.steps) * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.model, args.dtype),
                          "kernel": "conv3x3_kernel<dtype,rows,cout_blocks> (all instantiations; "
-                                   f"{flops_frame / 1e12:.3f} algorithmic TFLOP per frame over HIP-event device time)"},
+                                   f"{flops_frame / 1e12:.3f} algorithmic TFLOP per frame over HIP-event device time)",
+                         "launches_per_frame": launches,
+                         "flops_per_launch": round(flops_frame / launches),
+                         "avg_launch_us_overlapped": round(dev_s / (batch * args.steps) / launches * 1e6, 3)},
         }
+        if serial is not None:
+            rec["roofline"]["serial"] = {"achieved": round(flops_frame / serial / 1e12, 2),
+                                         "frac": round(flops_frame / serial / 1e12 / peak, 4),
+                                         "avg_launch_us": round(serial / launches * 1e6, 3),
+                                         "note": "one lane: launches run back to back, as under rocprofv3 --kernel-trace"}
         if not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             v, sample = cpu_baseline(args.model, sd, h, w, threads)

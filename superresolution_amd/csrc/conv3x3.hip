@@ -54,9 +54,15 @@ __device__ __forceinline__ void mma_chunk(f32x16& c, const u32x4& wfrag, const u
     }
 }
 
+// waves per workgroup (diagnostic builds may override)
+#ifndef SRMI_NW
+#define SRMI_NW 4
+#endif
+constexpr int kNW = SRMI_NW;
+
 template <int MB, int NB>
 struct ConvGeom {
-    static constexpr int TH = 4 * MB, PH = TH + 2, PW = kPatchW;
+    static constexpr int TH = kNW * MB, PH = TH + 2, PW = kPatchW;
     static constexpr int NCH = PH * PW * 2;                // 16-byte chunks of one pixel-patch stage
     static constexpr int A_PIECES = (NCH + 63) / 64;       // 1-KiB LDS-DMA pieces
     static constexpr int A_BYTES = A_PIECES * 1024;
@@ -301,8 +307,11 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 }
         __syncthreads();
         if (k.tid < 32 * NB) {
-            const float s = (lds_red[k.tid] + lds_red[32 * NB + k.tid]) +
-                            (lds_red[2 * 32 * NB + k.tid] + lds_red[3 * 32 * NB + k.tid]);
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < kNW; wv += 4)
+                s += (lds_red[wv * 32 * NB + k.tid] + lds_red[(wv + 1) * 32 * NB + k.tid]) +
+                     (lds_red[(wv + 2) * 32 * NB + k.tid] + lds_red[(wv + 3) * 32 * NB + k.tid]);
             const int cq = k.ct * 32 * NB + k.tid;
             if (cq < p.cout_real)
                 p.chansum[((long long)k.n * (p.tiles_x * p.tiles_y) + k.tile) * p.cout_real + cq] = s;
@@ -331,11 +340,11 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 }
 
 template <int DT, int MB, int NB>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     using G = ConvGeom<MB, NB>;
     constexpr int TH = G::TH, PW = G::PW;
-    constexpr int APW = (G::A_PIECES + 3) / 4, BPW = (G::B_PIECES + 3) / 4;  // pieces per wave
+    constexpr int APW = (G::A_PIECES + kNW - 1) / kNW, BPW = (G::B_PIECES + kNW - 1) / kNW;  // pieces per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
         const int srcW = p.in_up2 ? (p.w >> 1) : p.w;
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
-            const int i = (wave + 4 * j) * 64 + lane;
+            const int i = (wave + kNW * j) * 64 + lane;
             const int pp = i >> 1;
             const int c = (i & 1) ^ ((pp >> 3) & 1);
             const int rho = pp / PW, xi = pp - rho * PW;
@@ -393,12 +402,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
     constexpr int PPW = APW + BPW;
     auto issue_piece = [&](const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rb, char* abuf, const int q) {
         if (q < APW) {
-            const int k = wave + 4 * q;
+            const int k = wave + kNW * q;
             if (k < G::A_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(abuf + k * 1024),
                                                          16, aoff[q < APW ? q : 0], 0, 0, 0);
         } else {
-            const int k = wave + 4 * (q - APW);
+            const int k = wave + kNW * (q - APW);
             if (k < G::B_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(abuf + G::A_BYTES + k * 1024),
                                                          16, k * 1024 + lane * 16, 0, 0, 0);
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
     // [workgroup][wave][40]; slot 39 holds (XCC_ID << 32) | HW_ID
     unsigned long long* stamp_buf = (unsigned long long*)p.tail_out;
     int stamp_i = 0;
-    const size_t stamp_base = (((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 40;
+    const size_t stamp_base = (((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kNW + wave) * 40;
     if (stamp_buf && lane == 0) {
         unsigned hw_, xcc_;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
@@ -454,9 +463,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
     // counted vmcnt wait must leave outstanding to keep the NEXT stage in flight.
     int my_pieces = 0;
 #pragma unroll
-    for (int j = 0; j < APW; ++j) my_pieces += (wave + 4 * j < G::A_PIECES) ? 1 : 0;
+    for (int j = 0; j < APW; ++j) my_pieces += (wave + kNW * j < G::A_PIECES) ? 1 : 0;
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) my_pieces += (wave + 4 * j < G::B_PIECES) ? 1 : 0;
+    for (int j = 0; j < BPW; ++j) my_pieces += (wave + kNW * j < G::B_PIECES) ? 1 : 0;
     my_pieces = __builtin_amdgcn_readfirstlane(my_pieces);
 
     STAMP();
@@ -543,8 +552,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
         // Per step: the first MFMAs of the current set make the compiler wait for that set alone
         // (nothing else is outstanding yet); then the next set's ds_reads are issued and run
         // under the remaining MFMAs, so the following step's wait finds them complete.
-        Frag f0, f1;
         mfma_i = 0;
+#ifdef SRMI_SINGLE_FRAG  // diagnostic build: one fragment set, reloaded per horizontal tap (fewer registers)
+        Frag f0;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            load_frag(f0, Ab, Bb, dx);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f0, 0, after);
+            mma_frag(f0, 1, after);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
+        Frag f0, f1;
         load_frag(f0, Ab, Bb, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma_frag(f0, 0, after);
@@ -562,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ConvParams p) {
         mma_frag(f0, 0, after);
         mma_frag(f0, 1, after);
         __builtin_amdgcn_sched_barrier(0);
+#endif
         STAMP();
         cur = cur + 1 == G::NS ? 0 : cur + 1;
     }
@@ -610,7 +631,7 @@ static int launch(const ConvParams& p, hipStream_t stream) {
         configured = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y, p.cout / (32 * NB), p.n);
-    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB>), grid, dim3(64 * kNW), lds, stream, p);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
@@ -635,7 +656,7 @@ using namespace srmi;
 
 extern "C" int srmi_conv3x3_tiles(int h, int w, int rows_per_wave) {
     const int mb = rows_per_wave ? rows_per_wave : default_rows_per_wave();
-    const int th = 4 * mb;
+    const int th = kNW * mb;
     return ((w + kTileW - 1) / kTileW) * ((h + th - 1) / th);
 }
 
@@ -678,7 +699,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.ps_r = r;
     p.ps_c = d->cout / (r * r);
     p.tiles_x = (d->w + kTileW - 1) / kTileW;
-    p.tiles_y = (d->h + 4 * mb - 1) / (4 * mb);
+    p.tiles_y = (d->h + kNW * mb - 1) / (kNW * mb);
     p.tail_mode = d->tail_mode; p.tail_round = d->tail_round;
     p.in = to_view(d->in);
     {
