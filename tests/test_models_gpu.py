@@ -95,6 +95,70 @@ def test_bench_configuration_full_size_frame(trunk_f32):
         assert diff.max() <= 1 and O.psnr_u8(got, ref) >= 50.0
 
 
+def test_edsr_batch_configuration_full_size():
+    """EDSR x4 (32 blocks x 256 features) on 256x256 frames: frame 0 of a batch against the oracle, and the
+    frames of a 32-frame batch against the same frames run alone (bit for bit)."""
+    meta = _u8_case("edsr")
+    model, sd = H.build_model(meta, "f16")
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    imgs = np.stack([synth.smooth_image(256, 256, 40)] + [synth.random_image(256, 256, 41 + i) for i in range(3)])
+    got = model.forward_u8(imgs, _lib.ROUND_HALF_UP).numpy()
+    assert got.shape == (4, 1024, 1024, 3)
+    with torch.no_grad():
+        ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(imgs[0])), O.ROUND_HALF_UP)[0]
+    diff = np.abs(got[0].astype(np.int32) - ref.astype(np.int32))
+    print(f"edsr 256x256 f16: max u8 diff {diff.max()}, PSNR {O.psnr_u8(got[0], ref):.2f} dB")
+    assert diff.max() <= 1 and O.psnr_u8(got[0], ref) >= 50.0
+    eng = model.engine()
+    batch = torch.from_numpy(np.concatenate([imgs] * 8)).cuda()          # 32 frames
+    out = eng.forward_u8(batch).cpu().numpy()
+    for i in range(32):
+        assert np.array_equal(out[i], got[i % 4]), i
+
+
+def test_rcan_configuration_full_size_frame():
+    """RCAN x4 (10 groups x 20 blocks) on a 510x339 frame against the oracle: the channel-attention means run
+    over 172 890 pixels in 464 tile partial sums."""
+    meta = _u8_case("rcan")
+    model, sd = H.build_model(meta, "f16")
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    img = synth.smooth_image(339, 510, 50)
+    got = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    with torch.no_grad():
+        ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(img)), O.ROUND_HALF_UP)[0]
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    print(f"rcan 510x339 f16: max u8 diff {diff.max()}, PSNR {O.psnr_u8(got, ref):.2f} dB")
+    assert got.shape == (1356, 2040, 3)
+    assert diff.max() <= 1 and O.psnr_u8(got, ref) >= 50.0
+
+
+def test_1080p_frame_whole_and_halo_tiled():
+    """Real-ESRGAN x4plus on a 1920x1080 frame -> 7680x4320: the whole frame in one call, and the same frame as
+    a 2x4 grid of halo-overlapped tiles (the multi-GPU tile mode).  The oracle is too slow at this size, so the
+    test uses size-independent properties: a repeated run is bit-identical, the tiled result stays within a
+    bounded error of the whole frame (the 32-px halo is far below the 348-px receptive field, so seams are
+    approximate by design), and a corner block far from every seam agrees exactly."""
+    from superresolution_amd import sharding
+    meta = dict(arch="rrdbnet", num_block=23, scale=4, seed=0, input="unit")
+    model, _ = H.build_model(meta, "f16", trunk_f32=False)
+    eng = model.engine()
+    img = torch.from_numpy(synth.smooth_image(1080, 1920, 7)).cuda()
+    whole = eng.forward_u8(img)
+    assert tuple(whole.shape) == (4320, 7680, 3)
+    again = eng.forward_u8(img)
+    assert torch.equal(whole, again)
+    tiled = sharding.upscale_tiled(lambda t: eng.forward_u8(t), img, 4, 540, 480, 32)
+    assert tuple(tiled.shape) == (4320, 7680, 3)
+    w_np, t_np = whole.cpu().numpy(), tiled.cpu().numpy()
+    d = np.abs(w_np.astype(np.int32) - t_np.astype(np.int32))
+    psnr = O.psnr_u8(w_np, t_np)
+    print(f"1080p halo 32: max diff {d.max()}, differing {100 * (d != 0).mean():.3f}%, PSNR {psnr:.1f} dB")
+    assert psnr >= 45.0
+    # the frame's outer border band belongs to border tiles whose own borders coincide with the frame's: padding
+    # is identical there, so the top-left corner block (far from any seam) must agree exactly
+    assert np.array_equal(w_np[:256, :256], t_np[:256, :256])
+
+
 def test_halo_tiling_is_exact_when_halo_covers_the_receptive_field():
     """Tiles (+halo) of a frame upscaled independently and stitched == the whole frame upscaled,
     bit for bit, once the halo covers the receptive field (1 RRDB: 15 convs + conv_body + tail)."""
