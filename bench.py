@@ -122,6 +122,9 @@ def main():
                     help="keep an extra f32 copy of the residual trunk (default: f16 trunk, which meets the same "
                          "1-LSB / 50 dB parity bound at this workload, tests/test_models_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier and the max-over-ranks reduce (gloo: rehearsal of the "
+                         "multi-rank path on a box with fewer GPUs than ranks; ranks then share devices)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,11 +135,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     # workload: the configuration BASELINE.json's metric is quoted on
     defaults = {"rrdbnet": (339, 510, 12), "rcan": (339, 510, 12), "edsr": (256, 256, 36)}
@@ -193,7 +201,7 @@ def main():
     dev_s = ev0.elapsed_time(ev1) / 1e3
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([wall, dev_s], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, dev_s], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_s = float(t[0]), float(t[1])
     torch.cuda.synchronize()
@@ -254,7 +262,7 @@ def main():
                                          "frac": round(flops_frame / serial / 1e12 / peak, 4),
                                          "avg_launch_us": round(serial / launches * 1e6, 3),
                                          "note": "one lane: launches run back to back, as under rocprofv3 --kernel-trace"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             v, sample = cpu_baseline(args.model, sd, h, w, threads)
             rec["cpu_baseline"] = {"value": round(v, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
