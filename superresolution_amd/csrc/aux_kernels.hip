@@ -165,44 +165,43 @@ __global__ __launch_bounds__(256) void ca_apply_kernel(TView y, TView x, const f
     }
 }
 
-// Per-(n, c) sums over all pixels: each workgroup reduces a pixel segment of one 4-channel group
-// slice with wavefront shuffles, then one float atomic per channel per workgroup.
+// Per-(n, c) sums over all pixels.  One workgroup = one 16-channel span x a segment of pixels; a thread
+// reads 8 channels of a pixel (16 bytes on half tensors), so a wave reads contiguous runs.  Threads
+// with the same 8-channel half are reduced with wavefront shuffles, the four waves through LDS, and
+// each workgroup ends with one float atomic per channel.
 __global__ __launch_bounds__(256) void channel_sums_kernel(TView x, long long hw, int c, float* sums, int seg) {
-    const int groups = c >> 2;
     const int n = blockIdx.z;
-    const int gslot = threadIdx.x % 16;              // 16 channel groups in flight per block
-    const int g = blockIdx.y * 16 + gslot;
-    const int prow = threadIdx.x / 16;               // 16 pixel rows per block step
+    const int sub = threadIdx.x & 1;
+    const int ch = blockIdx.y * 16 + sub * 8;
     const long long p_begin = (long long)blockIdx.x * seg;
     const long long p_end = p_begin + seg < hw ? p_begin + seg : hw;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g < groups) {
-        for (long long pix = p_begin + prow; pix < p_end; pix += 16) {
-            float v[4];
-            load4(x, n, pix, g * 4, v);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ch < c) {
+        for (long long pix = p_begin + (threadIdx.x >> 1); pix < p_end; pix += 128) {
+            float v[8];
+            load8(x, n, pix, ch, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += v[j];
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
         }
     }
-    // lanes with equal gslot: xor over bits 4,5 inside the wave, then 4 waves through LDS
-    __shared__ float red[4][16][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        acc[j] += __shfl_xor(acc[j], 16);
-        acc[j] += __shfl_xor(acc[j], 32);
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = 2; m < 64; m <<= 1) acc[j] += __shfl_xor(acc[j], m);
     }
+    __shared__ float red[4][2][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < 16) {
+    if (lane < 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[wave][lane][j] = acc[j];
+        for (int j = 0; j < 8; ++j) red[wave][lane][j] = acc[j];
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int gs = threadIdx.x >> 2, j = threadIdx.x & 3;
-        const int gg = blockIdx.y * 16 + gs;
-        if (gg < groups) {
-            const float s = (red[0][gs][j] + red[1][gs][j]) + (red[2][gs][j] + red[3][gs][j]);
-            atomicAdd(sums + (long long)n * c + gg * 4 + j, s);
+    if (threadIdx.x < 16) {
+        const int sb = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int cc = blockIdx.y * 16 + sb * 8 + j;
+        if (cc < c) {
+            const float s = (red[0][sb][j] + red[1][sb][j]) + (red[2][sb][j] + red[3][sb][j]);
+            atomicAdd(sums + (long long)n * c + cc, s);
         }
     }
 }
@@ -391,13 +390,17 @@ extern "C" int srmi_ca_apply(const srmi_tensor_t* y, const srmi_tensor_t* x, con
 
 extern "C" int srmi_channel_sums(const srmi_tensor_t* x, int n, int h, int w, int c, float* sums, void* hip_stream) {
     if (!x || !x->ptr || !sums) SRMI_FAIL("srmi_channel_sums: null pointer");
-    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 4) SRMI_FAIL("srmi_channel_sums: bad shape");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8) SRMI_FAIL("srmi_channel_sums: bad shape (c must be a multiple of 8)");
     hipStream_t s = (hipStream_t)hip_stream;
     SRMI_HIP(hipMemsetAsync(sums, 0, (size_t)n * c * sizeof(float), s));
     const long long hw = (long long)h * w;
-    const int seg = 4096;
-    dim3 grid((unsigned)((hw + seg - 1) / seg), (unsigned)((c / 4 + 15) / 16), (unsigned)n);
-    hipLaunchKernelGGL(channel_sums_kernel, grid, dim3(256), 0, s, to_view(*x), hw, c, sums, seg);
+    // about 768 workgroups in all (three per CU; more only adds contention on the per-channel atomics),
+    // segments a multiple of the 128 pixels a workgroup reads per step
+    const int spans = (c + 15) / 16;
+    long long seg = (hw * spans * n + 767) / 768;
+    seg = (seg + 127) / 128 * 128;
+    dim3 grid((unsigned)((hw + seg - 1) / seg), (unsigned)spans, (unsigned)n);
+    hipLaunchKernelGGL(channel_sums_kernel, grid, dim3(256), 0, s, to_view(*x), hw, c, sums, (int)seg);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
