@@ -210,3 +210,13 @@ def test_model_create_validates_arguments():
     assert L.srmi_model_create(C.byref(d), C.byref(h)) == -1
     assert b"not supported" in L.srmi_last_error()
     assert L.srmi_model_create(None, C.byref(h)) == -1
+
+
+def test_demo_cli_usage_and_family_heuristic(capsys):
+    from superresolution_amd import demo
+    assert demo.main(["demo"]) == -1
+    assert "Usage:" in capsys.readouterr().out
+    assert demo.main(["demo", "a", "b", "c", "--model", "nope"]) == -1
+    assert demo.family_from_name("/x/EDSR_x4.srmi") == "edsr"
+    assert demo.family_from_name("RCAN_BIX4.srmi") == "rcan"
+    assert demo.family_from_name("RealESRGAN_x4plus.srmi") == "realesrgan"

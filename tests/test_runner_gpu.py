@@ -130,3 +130,26 @@ def test_wrong_architecture_file_is_rejected(tmp_path):
     ctx = RealesrganCtx()
     assert L.realesrgan_init(path.encode(), C.byref(ctx)) == -1
     assert b"architecture" in L.srmi_last_error()
+
+
+def test_demo_cli_png_in_png_out(tmp_path, capsys):
+    """The command-line demo (the reference's main.cpp flow) writes the same pixels as the runner call."""
+    from PIL import Image
+    from superresolution_amd import demo
+    meta = dict(arch="rrdbnet", num_block=1, scale=4, seed=43, input="unit")
+    model, _ = H.build_model(meta, "f16")
+    wpath = str(tmp_path / "RealESRGAN_x4plus_demo.srmi")
+    export.save_weights(model, wpath)
+    img = synth.smooth_image(339, 510, 5)
+    ipath, opath = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    Image.fromarray(img, "RGB").save(ipath)
+    assert demo.main(["demo", wpath, ipath, opath]) == 0
+    text = capsys.readouterr().out
+    assert "Output:   2040x1356" in text and "Scale:    x4" in text and "FPS:" in text
+    got = np.asarray(Image.open(opath))
+    want = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    assert got.shape == (1356, 2040, 3) and np.array_equal(got, want)
+    # failures return -1 like main.cpp: wrong argument count, missing image, missing model
+    assert demo.main(["demo", wpath, ipath]) == -1
+    assert demo.main(["demo", wpath, str(tmp_path / "missing.png"), opath]) == -1
+    assert demo.main(["demo", str(tmp_path / "missing.srmi"), ipath, opath]) == -1
