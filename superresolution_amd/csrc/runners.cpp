@@ -77,8 +77,11 @@ static int load_model(const char* path, int want_arch, srmi_model_t** out, srmi_
             int64_t dims[8];
             if (nd && !read_exact(f, dims, sizeof(int64_t) * nd)) goto bad;
             int64_t n = 1;
-            for (int k = 0; k < nd; ++k) n *= dims[k];
-            if (n < 0 || n > (1ll << 31)) goto bad;
+            for (int k = 0; k < nd; ++k) {
+                if (dims[k] < 0 || dims[k] > (1ll << 31)) goto bad;
+                n *= dims[k];
+                if (n > (1ll << 31)) goto bad;
+            }
             data.resize((size_t)n);
             if (!read_exact(f, data.data(), sizeof(float) * (size_t)n)) goto bad;
             if (srmi_model_set_tensor(m, name.c_str(), data.data(), dims, nd)) { fclose(f); srmi_model_destroy(m); return -1; }
