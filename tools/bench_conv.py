@@ -25,7 +25,7 @@ def bench(cin, cout, h, w, mb, dt=_lib.F16, n=1, iters=50, **kw):
 if __name__ == "__main__":
     h, w = 339, 510
     if len(sys.argv) > 2: h, w = int(sys.argv[1]), int(sys.argv[2])
-    print(f"frame {w}x{h}; SRMI_DEBUG={os.environ.get('SRMI_DEBUG')}")
+    print(f"frame {w}x{h}; library {os.environ.get('SRMI_LIB', 'in-tree')}")
     for cout in (32, 64):
         for cin in (64, 128, 192, 384, 768):
             row = []
