@@ -45,14 +45,17 @@ class Engine:
         self.scale = scale
         self.device = torch.device("cuda", device)
         h = C.c_void_p()
+        # the destructor may run while the interpreter shuts down, when module globals are already gone:
+        # keep the loaded library on the instance
+        self._destroy = lib().srmi_model_destroy
         check(lib().srmi_model_create(C.byref(d), C.byref(h)), "srmi_model_create")
         self._h = h
         self._finalized = False
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().srmi_model_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._destroy(h)
 
     __del__ = close
 
