@@ -132,7 +132,7 @@ __device__ __forceinline__ void st8(const TView& t, int n, long long pix, int c,
         if constexpr (TYPE == SRMI_F16) {
             f16x8 x;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = (_Float16)v[j];
+            for (int j = 0; j < 8; ++j) x[j] = to_f16_sat(v[j]);
             *(f16x8*)a = x;
         } else {
             bf16x8 x;

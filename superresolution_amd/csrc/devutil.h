@@ -14,6 +14,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// f32 -> f16 with saturation: a value beyond the half range is stored as +-65504 instead of +-inf, so one
+// large activation cannot turn the rest of the network into NaNs (in-range values round as a plain cast)
+__device__ __forceinline__ _Float16 to_f16_sat(float v) {
+    return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+}
+
 // ---- 4-channel accessors on plane tensors (runtime dtype, wave-uniform branches) -----------------
 __device__ __forceinline__ char* chan_addr(const TView& t, int n, long long pix, int c) {
     char* base = t.ptr + (long long)n * t.img_stride_b;
@@ -41,7 +47,7 @@ __device__ __forceinline__ void store4(const TView& t, int n, long long pix, int
         f32x4 x = {v[0], v[1], v[2], v[3]};
         *(f32x4*)a = x;
     } else if (t.dtype == SRMI_F16) {
-        f16x4 x = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        f16x4 x = {to_f16_sat(v[0]), to_f16_sat(v[1]), to_f16_sat(v[2]), to_f16_sat(v[3])};
         *(f16x4*)a = x;
     } else {
         bf16x4 x = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -76,7 +82,7 @@ __device__ __forceinline__ void store8(const TView& t, int n, long long pix, int
     } else if (t.dtype == SRMI_F16) {
         f16x8 x;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (_Float16)v[j];
+        for (int j = 0; j < 8; ++j) x[j] = to_f16_sat(v[j]);
         *(f16x8*)a = x;
     } else {
         bf16x8 x;

@@ -232,3 +232,18 @@ def test_bad_arguments_fail_loudly():
         ops.conv3x3(x, pc)
     with pytest.raises(_lib.SrmiError):
         ops.PackedConv(np.zeros((64, 50, 3, 3), np.float32), None, _lib.F16)  # cin not a plane multiple
+
+
+def test_f16_stores_saturate_instead_of_overflowing():
+    """Values beyond the half range are stored as +-65504, not +-inf (in-range values are unaffected)."""
+    n, h, w = 1, 12, 32
+    x = torch.full((n, 16, h, w), 100.0)
+    wt = torch.zeros(32, 16, 3, 3)
+    wt[:, :, 1, 1] = 50.0                     # centre tap only: 16 * 100 * 50 = 80000 > 65504
+    wt[1] = -wt[1]
+    wt[2] *= 0.5                              # 40000: representable
+    pc = ops.PackedConv(wt.numpy(), np.zeros(32, np.float32), _lib.F16)
+    out = ops.conv3x3(ops.Planes.from_nchw(x, _lib.F16), pc).to_nchw().cpu()
+    assert torch.isfinite(out).all()
+    assert float(out[0, 0].min()) == 65504.0 and float(out[0, 1].max()) == -65504.0
+    assert float(out[0, 2].min()) == 40000.0 == float(out[0, 2].max())
