@@ -175,6 +175,41 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
     const bool has_res2 = generic ? p.res2.ptr != nullptr : RES2;
     const bool has_out = generic ? p.out.ptr != nullptr : OUT != -1;
     const bool has_out2 = generic ? p.out2.ptr != nullptr : OUT2 != -1;
+    // Half-precision residuals of all MB rows are requested before anything else, as raw 16-byte
+    // loads: their latencies overlap each other and the bias / exchange work instead of being paid
+    // once per row and residual.  (f32 residuals and 64-wide tiles would need twice the registers
+    // and keep the per-row loads below.)
+    constexpr bool prefetch_res = !generic && NB == 1 && (RES == SRMI_F16 || RES == SRMI_BF16);
+    u32x4 raw1[prefetch_res ? MB : 1][NB][2], raw2[(prefetch_res && RES2) ? MB : 1][NB][2];
+    if constexpr (prefetch_res) {
+#pragma unroll
+        for (int r = 0; r < MB; ++r) {
+            const int y = k.y0 + k.wave * MB + r;
+            const long long pix = ((y < p.h) && (x < p.w)) ? (long long)y * p.w + x : 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int c = (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh;
+                    raw1[r][b][q] = *(const u32x4*)(p.res1.ptr + (long long)k.n * p.res1.img_stride_b +
+                                                    (long long)(c >> 4) * p.res1.plane_stride_b + pix * 32 + (c & 15) * 2);
+                    if constexpr (RES2)
+                        raw2[r][b][q] = *(const u32x4*)(p.res2.ptr + (long long)k.n * p.res2.img_stride_b +
+                                                        (long long)(c >> 4) * p.res2.plane_stride_b + pix * 32 + (c & 15) * 2);
+                }
+        }
+    }
+    auto unpack8 = [](const u32x4& raw, float (&o)[8]) {
+        if constexpr (RES == SRMI_F16) {
+            const f16x8 h = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (float)h[j];
+        } else {
+            const bf16x8 h = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (float)h[j];
+        }
+    };
 #pragma unroll
     for (int r = 0; r < MB; ++r) {
         const int y = k.y0 + k.wave * MB + r;
@@ -216,7 +251,10 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) ld8<RES>(p.res1, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, rr[b][q]);
+                for (int q = 0; q < 2; ++q) {
+                    if constexpr (prefetch_res) unpack8(raw1[r][b][q], rr[b][q]);
+                    else ld8<RES>(p.res1, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, rr[b][q]);
+                }
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -229,7 +267,10 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) ld8<RES>(p.res2, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, rr[b][q]);
+                for (int q = 0; q < 2; ++q) {
+                    if constexpr (prefetch_res && RES2) unpack8(raw2[r][b][q], rr[b][q]);
+                    else ld8<RES>(p.res2, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, rr[b][q]);
+                }
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
