@@ -159,6 +159,32 @@ def test_1080p_frame_whole_and_halo_tiled():
     assert np.array_equal(w_np[:256, :256], t_np[:256, :256])
 
 
+@pytest.mark.parametrize("arch", ["rrdbnet", "edsr", "rcan"])
+def test_edge_inputs_constant_frames_and_tiny_sizes(arch):
+    """Constant black / white frames (every pixel clamps or sits on the border of the u8 range) and
+    degenerate sizes (1x1, one row, one column, one pixel more than a tile) against the oracle, f16."""
+    meta = _u8_case(arch)
+    if arch == "rrdbnet":
+        meta = dict(meta, num_block=2)
+    elif arch == "edsr":
+        meta = dict(meta, n_resblocks=3, n_feats=64)
+    else:
+        meta = dict(meta, n_resgroups=2, n_resblocks=2)
+    model, sd = H.build_model(meta, "f16")
+    cases = [np.zeros((24, 40, 3), np.uint8), np.full((24, 40, 3), 255, np.uint8)]
+    cases += [synth.random_image(h, w, 60 + i) for i, (h, w) in enumerate([(1, 1), (1, 37), (29, 1), (13, 33), (2, 2)])]
+    for img in cases:
+        got = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+        with torch.no_grad():
+            if arch == "rrdbnet":
+                ref = O.post_unit(H.oracle_forward(meta, sd, O.pre_unit(img)), O.ROUND_HALF_UP)[0]
+            else:
+                ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(img)), O.ROUND_HALF_UP)[0]
+        assert got.shape == ref.shape == (img.shape[0] * 4, img.shape[1] * 4, 3)
+        diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        assert diff.max() <= 1, (arch, img.shape, int(diff.max()))
+
+
 def test_halo_tiling_is_exact_when_halo_covers_the_receptive_field():
     """Tiles (+halo) of a frame upscaled independently and stitched == the whole frame upscaled,
     bit for bit, once the halo covers the receptive field (1 RRDB: 15 convs + conv_body + tail)."""
