@@ -24,6 +24,8 @@
 // Stages form a ring of SRMI_RING slots (2: with the 12-row tile a workgroup then needs under 53 KiB
 // and three fit a CU, which beats a deeper ring at two per CU); the next stage's pieces are issued
 // between the multiply steps of the current one, counted vmcnt waits and one raw s_barrier per stage.
+// Reductions of 8 stages or more run a variant of the loop whose barrier sits behind the stage's
+// last LDS read instead of its last MFMA (see the main loop).
 // LDS rows are 32 bytes; the 16-byte chunk index is XORed with (row>>3)&1 so that the 16-lane
 // groups of ds_read_b128 touch 16 different bank slots (conflict-free).
 //
@@ -557,6 +559,79 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
     constexpr int GAP = (9 * MB * NB) / PPW;  // multiply steps between two DMA pieces
     static_assert(GAP >= 1, "a stage needs at least as many multiply steps as DMA pieces per wave");
 
+    // Two main loops; long reductions take the first (measured: +3 % on EDSR's 16-stage layers, +1 % on
+    // the 8-12-stage layers of a dense block, but -4 % on 4-stage layers, which keep the second).
+    constexpr int kCarriedMinStages = 8;
+    bool carried = false;
+    if constexpr (G::NS == 2) carried = nstage >= kCarriedMinStages;
+    if (carried) {
+    // Fragment-carried pipeline (two-slot ring).  The barrier of a stage sits after the LAST LDS read
+    // of the stage has returned, not after its last MFMA: the final third of the stage's MFMAs only
+    // needs registers, so it runs behind the barrier, together with the first fragment reads of the
+    // next stage and the DMA issue of the stage after that.  No wave ever waits for LDS with an
+    // empty matrix pipe at a stage boundary.
+    // both slots are free at the start: stage 1 is requested right behind stage 0, and only stage 0
+    // has to have landed before the first fragment reads
+    if (nstage > 1) {
+        issue(1, 1);
+        wait_vmcnt_le(my_pieces);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    Frag fr0, fr1;
+    load_frag(fr0, smem, smem + G::A_BYTES + lx * 32, 0);
+    auto none = [](const int) {};
+    auto run_stage = [&](Frag& fa, Frag& fb, const int s, const int cur) {
+        const char* Ab = smem + cur * G::STAGE_BYTES;
+        const char* Bb = Ab + G::A_BYTES + lx * 32;
+        load_frag(fb, Ab, Bb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag(fa, 0, none);
+        mma_frag(fa, 1, none);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag(fa, Ab, Bb, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag(fb, 0, none);
+        mma_frag(fb, 1, none);
+        __builtin_amdgcn_sched_barrier(0);
+        // every LDS read of stage s has been issued: once they and this wave's share of stage s+1
+        // have landed, the barrier tells everybody that slot `cur` may be overwritten and that the
+        // other slot is complete
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = s + 2 < nstage;
+        {
+            // unconditional (after the last stage the values are simply unused): a branch here makes
+            // the compiler's waitcnt bookkeeping pessimistic and the MFMAs below would wait for these reads
+            const char* An = smem + (cur ^ 1) * G::STAGE_BYTES;
+            load_frag(fb, An, An + G::A_BYTES + lx * 32, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int sn = more ? s + 2 : s;
+        const auto ra = pixel_rsrc(sn);
+        const auto rb = weight_rsrc(sn);
+        char* nbuf = smem + cur * G::STAGE_BYTES;
+        mfma_i = 0;
+        auto after = [&](const int i) {
+            if (i < PPW) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_piece(ra, rb, nbuf, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        static_assert(3 * MB * NB >= PPW, "the last third of a stage must have a slot for every DMA piece");
+        mma_frag(fa, 0, after);
+        mma_frag(fa, 1, after);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int s = 0; s < nstage; s += 2) {
+        run_stage(fr0, fr1, s, 0);
+        if (s + 1 < nstage) run_stage(fr1, fr0, s + 1, 1);
+    }
+    } else {
     int cur = 0;  // ring slot of stage s
     for (int s = 0; s < nstage; ++s) {
         // stage s has landed once at most the younger stage's pieces are still outstanding
@@ -627,6 +702,7 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
         STAMP();
         cur = cur + 1 == G::NS ? 0 : cur + 1;
     }
+    }  // classic loop
     // the epilogue reuses the stage buffers (channel sums) and reads the bias: all waves must be
     // out of the main loop first
     __syncthreads();
