@@ -444,6 +444,15 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
     // are weight pieces.
     constexpr int PPW = APW + BPW;
     auto issue_piece = [&](const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rb, char* abuf, const int q) {
+#ifdef SRMI_ABL_NO_DMA  // timing ablation (wrong results): nothing is staged after the prologue
+        return;
+#endif
+#ifdef SRMI_ABL_NO_DMA_A  // timing ablation: no pixel pieces
+        if (q < APW) return;
+#endif
+#ifdef SRMI_ABL_NO_DMA_B  // timing ablation: no weight pieces
+        if (q >= APW) return;
+#endif
         if (q < APW) {
             const int k = wave + kNW * q;
             if (k < G::A_PIECES)
@@ -524,6 +533,9 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
         u32x4 pf[MB + 2];
     };
     auto load_frag = [&](Frag& f, const char* Ab, const char* Bb, const int dx) {
+#ifdef SRMI_ABL_NO_LDS  // timing ablation (wrong results): fragments are read once and reused
+        if (dx != 0 || Ab != smem) return;
+#endif
 #pragma unroll
         for (int rho = 0; rho < MB + 2; ++rho) {
             if (rho < 3) {
