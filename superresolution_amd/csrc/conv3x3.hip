@@ -753,11 +753,14 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
 template <int DT, int MB, int NB>
 static int launch(const ConvParams& p, hipStream_t stream) {
     constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL;
-    static bool configured = false;
-    if (!configured) {
+    // the dynamic-LDS limit is a per-device attribute of the function: set it once on every device used
+    static bool configured[64] = {};
+    int dev = 0;
+    SRMI_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !configured[dev]) {
         SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+        if (dev >= 0 && dev < 64) configured[dev] = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y, p.cout / (32 * NB), p.n);
     hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB>), grid, dim3(64 * kNW), lds, stream, p);
