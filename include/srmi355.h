@@ -82,7 +82,8 @@ typedef struct {
  *   v   = act(conv(in) + bias)
  *   v   = v * alpha + res1          (if res1.ptr)   ResBlock / RDB / RCAB-group residuals
  *   v   = v * beta  + res2          (if res2.ptr)   RRDB outer residual (realesrgan_model.py:49)
- *   out[.., out_c0 ..]   = v        (if out.ptr; cast to out.dtype; PixelShuffle(ps_r) store)
+ *   out                  = v        (if out.ptr; cast to out.dtype, f16 saturating at +-65504; a view into
+ *                                    a wider tensor gives the dense block's concat; PixelShuffle(ps_r) store)
  *   out2                 = v        (if out2.ptr; second copy, usually the f32 trunk)
  *   chansum[n][tile][c]  = sum over the tile's pixels of v   (if chansum; CALayer pooling)
  *   tail: rgb = tail_mat * v[0:3] + tail_bias -> f32 NCHW, or clamp/scale/round -> u8 NHWC
