@@ -145,6 +145,23 @@ __device__ __forceinline__ void st8(const TView& t, int n, long long pix, int c,
     }
 }
 
+// Sum over the 32 lanes of each half wave, valid in lanes 31 and 63: six DPP adds on the vector pipe
+// (row shifts build the 16-lane row sums in lane 15 of every row, row_bcast:15 carries rows 0 and 2
+// into rows 1 and 3) instead of five cross-lane shuffles through the LDS crossbar.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+    float s = v + dpp_move<0x111, 0xf, 0xf>(v);      // row_shr:1
+    s += dpp_move<0x112, 0xf, 0xf>(v);                // row_shr:2
+    s += dpp_move<0x113, 0xf, 0xf>(v);                // row_shr:3  -> sums of 4 behind every lane
+    s += dpp_move<0x114, 0xf, 0xe>(s);                // row_shr:4, banks 1-3
+    s += dpp_move<0x118, 0xf, 0xc>(s);                // row_shr:8, banks 2-3 -> lane 15 of a row = row sum
+    s += dpp_move<0x142, 0xa, 0xf>(s);                // row_bcast:15 into rows 1 and 3
+    return s;
+}
+
 // After the half-wave exchange a lane owns, for its pixel, the 8 consecutive channels
 // 16*q + 8*lh .. +7 of every 32-channel block (q = 0, 1): all tensor accesses are 16 or 32 bytes.
 template <int DT, int MB, int NB, int OUT, int RES, bool RES2, int OUT2>
@@ -335,7 +352,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
     }
 
     if (p.chansum) {
-        // deterministic tile sums: lanes -> wave (xor shuffles inside each 32-lane half), waves -> LDS
+        // deterministic tile sums: lanes -> wave (DPP adds inside each 32-lane half), waves -> LDS
         // (lds_red aliases the stage buffers, which nobody reads any more)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -343,10 +360,8 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float s = csum[b][q][j];
-#pragma unroll
-                    for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m);
-                    if (k.lx == 0) lds_red[k.wave * 32 * NB + b * 32 + 16 * q + 8 * k.lh + j] = s;
+                    const float s = half_wave_sum(csum[b][q][j]);
+                    if (k.lx == 31) lds_red[k.wave * 32 * NB + b * 32 + 16 * q + 8 * k.lh + j] = s;
                 }
         __syncthreads();
         if (k.tid < 32 * NB) {
