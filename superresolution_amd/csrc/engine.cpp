@@ -264,8 +264,7 @@ static srmi_tensor_t tv(const Buf& b, int c0 = 0) {
     return t;
 }
 
-static int pick_rows_per_wave(const srmi_model* m, int h, int w, int cout, int cout_tile, int ns) {
-    (void)w; (void)cout; (void)cout_tile; (void)ns;
+static int pick_rows_per_wave(const srmi_model* m, int h) {
     if (m->mb_override) return m->mb_override;
     // Three rows per wave (12-row tiles) is the fastest variant on every layer of the three networks
     // when kernels of several lanes share the CUs; only images shorter than one such tile use the
@@ -290,7 +289,7 @@ struct Exec {
         d.n = ns; d.h = h; d.w = w;
         d.cin = cw.cin; d.cout = cw.cout;
         d.in_up2 = up2; d.act = act; d.ps_r = cw.ps_r; d.cout_tile = cw.cout_tile;
-        d.rows_per_wave = force_mb ? force_mb : pick_rows_per_wave(m, h, w, cw.cout, cw.cout_tile, ns);
+        d.rows_per_wave = force_mb ? force_mb : pick_rows_per_wave(m, h);
         d.in = in;
         d.wpk = cw.wpk; d.bias = cw.bias;
         d.alpha = alpha; d.beta = beta;
@@ -311,7 +310,7 @@ struct Exec {
         d.n = ns; d.h = h; d.w = w;
         d.cin = cw.cin; d.cout = 3;
         d.ps_r = 1; d.cout_tile = cw.cout_tile;
-        d.rows_per_wave = pick_rows_per_wave(m, h, w, 3, cw.cout_tile, ns);
+        d.rows_per_wave = pick_rows_per_wave(m, h);
         d.in = in;
         d.wpk = cw.wpk; d.bias = cw.bias;
         d.alpha = d.beta = 1.f;
@@ -517,7 +516,7 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
                 const srmi_tensor_t in = tv(XT[k]), t = tv(Tm), y = tv(Y);
                 if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr)) return -1;
                 snprintf(name, sizeof(name), "body.%d.body.%d.body.2", g, b);
-                const int mb = pick_rows_per_wave(m, h, w, nf, 64, ns);
+                const int mb = pick_rows_per_wave(m, h);
                 if (ex->conv(name, t, h, w, SRMI_ACT_NONE, false, 1.f, nullptr, 1.f, nullptr, &y, nullptr, chansum, mb)) return -1;
                 const CaW& ca = m->cas[ca_index++];
                 if (srmi_ca_scale(chansum, ns, srmi_conv3x3_tiles(h, w, mb), nf, cr, h * w, ca.w1, ca.b1, ca.w2, ca.b2, scale, ex->stream)) return -1;

@@ -91,10 +91,17 @@ def upscale_tiled_sharded(forward_u8, img: torch.Tensor, scale: int, tile_h: int
     for slot, i in enumerate(mine):
         flat = pieces[i].reshape(-1)
         send[slot * tile_bytes:slot * tile_bytes + flat.numel()] = flat
+    # RCCL ("nccl") gathers device buffers over xGMI; gloo (CPU tests, rehearsals with fewer GPUs than ranks)
+    # only moves host memory, so device pieces are staged through the host for it
+    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+    if staged:
+        send = send.cpu()
     recv = [torch.empty_like(send) for _ in range(world)] if rank == gather_to else None
     dist.gather(send, recv, dst=gather_to, group=group)
     if rank != gather_to:
         return None
+    if staged:
+        recv = [r.to(dev) for r in recv]
     out_pieces = []
     for i, t in enumerate(tiles):
         r, slot = i % world, i // world
