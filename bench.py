@@ -34,10 +34,10 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}  # dense, MI355X
 
 
-def build_model(arch, dtype, trunk_f32, device):
+def build_model(arch, dtype, trunk_f32, device, growth_round8=True):
     from superresolution_amd import EDSR, RCAN, RRDBNet, synth
     if arch == "rrdbnet":
-        m = RRDBNet(compute_dtype=dtype, trunk_f32=trunk_f32, device=device)
+        m = RRDBNet(compute_dtype=dtype, trunk_f32=trunk_f32, device=device, growth_round8=growth_round8)
         sd = synth.rrdbnet_state_dict(seed=0)
     elif arch == "edsr":
         m = EDSR(compute_dtype=dtype, trunk_f32=trunk_f32, device=device)
@@ -123,6 +123,9 @@ def main():
                     help="keep an extra f32 copy of the residual trunk (default: f16 trunk, which meets the same "
                          "1-LSB / 50 dB parity bound at this workload, tests/test_models_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plain-f16", action="store_true",
+                    help="RRDBNet f16: keep 11 significant bits in the dense blocks' grown channels too "
+                         "(default: 8 there, srmi_model_set_growth_round8)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier and the max-over-ranks reduce (gloo: rehearsal of the "
                          "multi-rank path on a box with fewer GPUs than ranks; ranks then share devices)")
@@ -157,7 +160,7 @@ def main():
     from superresolution_amd import _lib, synth
     models, engs = [], []
     for _ in range(args.streams):
-        model, sd = build_model(args.model, args.dtype, args.trunk_f32, local_rank)
+        model, sd = build_model(args.model, args.dtype, args.trunk_f32, local_rank, not args.plain_f16)
         models.append(model)
         engs.append(model.engine())
         engs[-1].set_sweep(args.sweep)
@@ -248,7 +251,12 @@ def main():
                                    f"{batch} frames per GPU per step, u8 in HBM -> u8 in HBM",
                        "frames_per_gpu_per_step": batch, "sweep": args.sweep, "lanes": args.lanes,
                        "streams": args.streams,
-                       "trunk_f32": args.trunk_f32, "parallelism": f"frame-sharded x{world}, no collective"},
+                       "trunk_f32": args.trunk_f32,
+                       "precision": ("f16 operands, f32 accumulation; dense-block grown channels x1..x4 and the weights of "
+                                     "conv1-4 / grown columns of conv5 carry 8 significant bits")
+                       if (args.model == "rrdbnet" and args.dtype == "f16" and not args.plain_f16)
+                       else f"{args.dtype} operands, f32 accumulation",
+                       "parallelism": f"frame-sharded x{world}, no collective"},
             "ms_per_frame_per_gpu": round(dev_s / (batch * args.steps) * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.model, args.dtype),

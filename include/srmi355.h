@@ -70,8 +70,14 @@ typedef struct {
     int64_t img_stride;   /* elements between images */
     int64_t plane_stride; /* elements between planes */
     int32_t dtype;        /* SRMI_F32 / SRMI_F16 / SRMI_BF16 */
-    int32_t reserved;
+    int32_t flags;        /* SRMI_TENSOR_* bits, 0 = none */
 } srmi_tensor_t;
+
+/* Honoured on `out` of srmi_conv3x3: values are rounded to 8 significant bits (bfloat16's precision,
+ * round to nearest even) before they are stored in the tensor's own element type.  The matrix cores
+ * draw measurably less power on operands with short significands, so tensors that tolerate it (the
+ * grown channels x1..x4 of a dense block, realesrgan_model.py:27-30) are kept that way. */
+#define SRMI_TENSOR_ROUND8 1
 
 /*
  * 3x3, stride 1, zero-padding 1 convolution with fused epilogue; replaces
@@ -254,6 +260,13 @@ int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep);
  * directly.  Images are independent (realesrgan_model.py:96-123 has no cross-image op), so the
  * results do not depend on this setting. */
 int srmi_model_set_lanes(srmi_model_t* m, int lanes);
+/* RRDBNet with f16 compute only (default on; call before srmi_model_finalize): the grown channels
+ * x1..x4 of every dense block (realesrgan_model.py:27-30) and the weight columns that multiply them
+ * are rounded to 8 significant bits, the trunk x and everything else keep f16's 11.  Operands with
+ * short significands cost the matrix cores less power, the chip holds a higher clock, and the
+ * result stays within the half-precision parity bound (u8 diff <= 1 LSB, PSNR >= 50 dB); 0 gives
+ * plain f16 everywhere. */
+int srmi_model_set_growth_round8(srmi_model_t* m, int on);
 /* Algorithmic conv FLOPs (2*Cin*Cout*9 per output pixel of every conv) of one forward at
  * (h, w) input size. */
 double srmi_model_flops(const srmi_model_t* m, int h, int w);

@@ -28,7 +28,10 @@ class SrmiError(RuntimeError):
 
 class Tensor(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("img_stride", C.c_int64), ("plane_stride", C.c_int64),
-                ("dtype", C.c_int32), ("reserved", C.c_int32)]
+                ("dtype", C.c_int32), ("flags", C.c_int32)]
+
+
+TENSOR_ROUND8 = 1
 
 
 class ConvDesc(C.Structure):
@@ -68,7 +71,7 @@ EXPORTS = [
     "srmi_resize_bilinear_u8",
     "srmi_model_create", "srmi_model_destroy", "srmi_model_set_tensor", "srmi_model_num_keys",
     "srmi_model_key", "srmi_model_finalize", "srmi_model_forward_f32", "srmi_model_forward_u8",
-    "srmi_model_workspace_bytes", "srmi_model_set_sweep", "srmi_model_set_lanes", "srmi_model_flops", "srmi_model_set_rgb_shift",
+    "srmi_model_workspace_bytes", "srmi_model_set_sweep", "srmi_model_set_lanes", "srmi_model_set_growth_round8", "srmi_model_flops", "srmi_model_set_rgb_shift",
     "edsr_init", "edsr_release", "edsr_inference", "edsr_inference_ex",
     "rcan_init", "rcan_release", "rcan_inference", "rcan_inference_ex",
     "realesrgan_init", "realesrgan_release", "realesrgan_inference", "realesrgan_inference_ex",
@@ -129,6 +132,7 @@ def lib():
         L.srmi_model_workspace_bytes.restype = C.c_size_t
         L.srmi_model_set_sweep.argtypes = [C.c_void_p, C.c_int]
         L.srmi_model_set_lanes.argtypes = [C.c_void_p, C.c_int]
+        L.srmi_model_set_growth_round8.argtypes = [C.c_void_p, C.c_int]
         L.srmi_model_flops.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.srmi_model_flops.restype = C.c_double
         L.srmi_model_set_rgb_shift.argtypes = [C.c_void_p, C.POINTER(C.c_float)]

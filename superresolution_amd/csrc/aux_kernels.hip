@@ -379,7 +379,7 @@ extern "C" int srmi_ca_apply(const srmi_tensor_t* y, const srmi_tensor_t* x, con
     if (!y || !x || !y->ptr || !x->ptr || !scale || !out) SRMI_FAIL("srmi_ca_apply: null pointer");
     if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 16) SRMI_FAIL("srmi_ca_apply: bad shape (c must be a multiple of 16)");
     TView o2;
-    o2.ptr = nullptr; o2.img_stride_b = o2.plane_stride_b = 0; o2.dtype = 0; o2.pad = 0;
+    o2.ptr = nullptr; o2.img_stride_b = o2.plane_stride_b = 0; o2.dtype = 0; o2.flags = 0;
     if (out2) o2 = to_view(*out2);
     const long long hw = (long long)h * w;
     hipLaunchKernelGGL(ca_apply_kernel, dim3(grid_for(n * hw * (c / 8))), dim3(256), 0, (hipStream_t)hip_stream,

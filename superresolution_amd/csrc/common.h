@@ -30,7 +30,7 @@ struct TView {
     long long img_stride_b;
     long long plane_stride_b;
     int dtype;
-    int pad;
+    int flags;  // SRMI_TENSOR_* bits
 };
 
 static inline int dtype_size(int dt) { return dt == SRMI_F32 ? 4 : 2; }
@@ -45,7 +45,7 @@ static inline TView to_view(const srmi_tensor_t& t) {
     v.img_stride_b = (long long)t.img_stride * dtype_size(t.dtype);
     v.plane_stride_b = (long long)t.plane_stride * dtype_size(t.dtype);
     v.dtype = t.dtype;
-    v.pad = 0;
+    v.flags = t.flags;
     return v;
 }
 

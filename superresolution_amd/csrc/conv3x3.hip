@@ -298,7 +298,23 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                     for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] * p.beta + rr[b][q][j];
         }
         if (inside && !tail) {
+            if (has_out2) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        st8<OUT2>(p.out2, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, v[b][q]);
+            }
             if (has_out) {
+                if (p.out.flags & SRMI_TENSOR_ROUND8) {
+                    // 8 significant bits (round to nearest even), then the cast of the store below
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[b][q][j] = (float)(__bf16)v[b][q][j];
+                }
                 if (p.ps_r == 1) {
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
@@ -316,13 +332,6 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                             st8<OUT>(p.out, k.n, (long long)oy * ow + ox, cc, v[b][q]);
                         }
                 }
-            }
-            if (has_out2) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        st8<OUT2>(p.out2, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, v[b][q]);
             }
         }
         if (p.chansum) {

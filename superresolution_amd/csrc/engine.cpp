@@ -81,6 +81,9 @@ struct srmi_model {
     size_t ws_bytes = 0;
     int sweep = 1;
     int mb_override = 0;
+    // RRDBNet, f16: the grown channels x1..x4 of every dense block (and the weights that multiply them)
+    // carry 8 significant bits; the trunk keeps full f16 precision (see srmi_model_set_growth_round8)
+    bool growth_round8 = true;
 
     // Independent sweeps of one call run on `lanes` internal streams that fork from and join the
     // caller's stream, so that one sweep's launch gaps, prologues and epilogues overlap another's
@@ -206,12 +209,31 @@ static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
     cw.cout_tile = (cw.cout <= 32 || m->d.arch == SRMI_ARCH_RRDBNET) ? 32 : 64;
     if (getenv("SRMI_COUT_TILE")) cw.cout_tile = atoi(getenv("SRMI_COUT_TILE")) == 32 || cw.cout <= 32 ? 32 : 64;  // diagnostic
     cw.ps_r = ps_r;
+    std::vector<float> rounded;
+    const float* wsrc = w.data.data();
+    if (m->growth_round8 && m->d.arch == SRMI_ARCH_RRDBNET && m->cdt() == SRMI_F16 && name.find(".rdb") != std::string::npos) {
+        // rounded to bfloat16 precision (nearest even): every weight of conv1..4, whose outputs are
+        // themselves kept at 8 significant bits, and in conv5 the columns of the grown input
+        // channels [n_feats, cin); conv5's trunk columns keep f16 precision
+        const bool is_conv5 = name.size() >= 5 && name.compare(name.size() - 5, 5, "conv5") == 0;
+        rounded = w.data;
+        for (int o = 0; o < cw.cout; ++o)
+            for (int ci = is_conv5 ? m->d.n_feats : 0; ci < cw.cin; ++ci)
+                for (int t = 0; t < 9; ++t) {
+                    float& v = rounded[((size_t)o * cw.cin + ci) * 9 + t];
+                    uint32_t u;
+                    memcpy(&u, &v, 4);
+                    if ((u & 0x7f800000u) != 0x7f800000u) u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+                    memcpy(&v, &u, 4);
+                }
+        wsrc = rounded.data();
+    }
     int nbias = 0;
     const size_t bytes = srmi_pack_conv3x3_bytes(m->cdt(), cw.cout, cw.cin, cw.cout_tile, &nbias);
     if (!bytes) SRMI_FAIL("%s: unsupported conv shape [%d,%d,3,3] for this dtype", name.c_str(), cw.cout, cw.cin);
     std::vector<char> wp(bytes);
     std::vector<float> bp(nbias);
-    if (srmi_pack_conv3x3(m->cdt(), cw.cout, cw.cin, cw.cout_tile, ps_r, w.data.data(), b.data.data(), wp.data(), bp.data()))
+    if (srmi_pack_conv3x3(m->cdt(), cw.cout, cw.cin, cw.cout_tile, ps_r, wsrc, b.data.data(), wp.data(), bp.data()))
         return -1;
     if (dev_upload(m, wp.data(), bytes, &cw.wpk)) return -1;
     if (dev_upload(m, bp.data(), nbias * sizeof(float), (void**)&cw.bias)) return -1;
@@ -384,7 +406,8 @@ static int run_rrdbnet(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int 
             const srmi_tensor_t in = tv(D[k]);
             for (int j = 1; j <= 4; ++j) {
                 snprintf(name, sizeof(name), "body.%d.rdb%d.conv%d", i, r, j);
-                const srmi_tensor_t o = tv(D[k], nf + (j - 1) * gc);
+                srmi_tensor_t o = tv(D[k], nf + (j - 1) * gc);
+                if (m->growth_round8 && T == SRMI_F16) o.flags = SRMI_TENSOR_ROUND8;
                 if (ex->conv(name, in, h, w, SRMI_ACT_LRELU, false, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
             }
             snprintf(name, sizeof(name), "body.%d.rdb%d.conv5", i, r);
@@ -828,6 +851,13 @@ extern "C" size_t srmi_model_workspace_bytes(const srmi_model_t* m) { return m ?
 extern "C" int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep) {
     if (!m || images_per_sweep < 1) SRMI_FAIL("srmi_model_set_sweep: bad argument");
     m->sweep = images_per_sweep;
+    return 0;
+}
+
+extern "C" int srmi_model_set_growth_round8(srmi_model_t* m, int on) {
+    if (!m) SRMI_FAIL("srmi_model_set_growth_round8: null model");
+    if (m->finalized) SRMI_FAIL("srmi_model_set_growth_round8: call before srmi_model_finalize (the weights are packed there)");
+    m->growth_round8 = on != 0;
     return 0;
 }
 

@@ -35,7 +35,7 @@ class Engine:
     """Owns one `srmi_model_t`."""
 
     def __init__(self, arch, *, dtype, scale, n_feats, n_blocks, n_groups=0, grow_ch=0, reduction=0,
-                 res_scale=1.0, with_meanshift=False, trunk_f32=True, device=0):
+                 res_scale=1.0, with_meanshift=False, trunk_f32=True, device=0, growth_round8=True):
         d = _lib.ModelDesc()
         d.arch, d.dtype, d.scale = arch, dtype, scale
         d.n_feats, d.n_blocks, d.n_groups = n_feats, n_blocks, n_groups
@@ -51,6 +51,8 @@ class Engine:
         check(lib().srmi_model_create(C.byref(d), C.byref(h)), "srmi_model_create")
         self._h = h
         self._finalized = False
+        if not growth_round8:
+            check(lib().srmi_model_set_growth_round8(h, 0), "srmi_model_set_growth_round8")
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

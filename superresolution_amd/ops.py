@@ -97,7 +97,7 @@ class PackedConv:
 
 def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Planes = None,
             beta=1.0, res2: Planes = None, out: Planes = None, out_c0=0, out_dtype=None,
-            out2: Planes = None, chansum=False, rows_per_wave=0, tail=None):
+            out2: Planes = None, chansum=False, rows_per_wave=0, tail=None, out_round8=False):
     """act(conv(x)+b)*alpha+res1 (*beta+res2) -> out (see srmi_conv3x3 in include/srmi355.h).
 
     tail: None, or dict(mode=TAIL_*, mat=3x3, bias=3, lo, hi, scale, round) for the RGB layer.
@@ -122,6 +122,8 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
         if out is None:
             out = Planes(n, pc.cout // (r * r), h * r, w * r, pc.dtype if out_dtype is None else out_dtype)
         d.out = out.view(out_c0)
+        if out_round8:
+            d.out.flags = _lib.TENSOR_ROUND8
         d.out2 = out2.view() if out2 is not None else _NULL
         d.tail_mode = 0
         if chansum:

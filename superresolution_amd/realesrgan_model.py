@@ -45,8 +45,10 @@ class RRDBNet(HipModule):
     """x: f32 NCHW in [0,1] -> f32 NCHW (scale x larger), no clamp (realesrgan_model.py:96-123)."""
 
     def __init__(self, num_in_ch=3, num_out_ch=3, num_feat=64, num_block=23, num_grow_ch=32, scale=4,
-                 *, compute_dtype=None, trunk_f32=True, device=None):
+                 *, compute_dtype=None, trunk_f32=True, device=None, growth_round8=True):
         super().__init__(compute_dtype, trunk_f32, device)
+        # f16 compute only: the dense blocks' grown channels carry 8 significant bits (srmi_model_set_growth_round8)
+        self._srmi_growth_round8 = bool(growth_round8)
         if scale not in (2, 4):
             raise ValueError(f"Unsupported scale: {scale}. Supported scales: 2, 4")
         if num_in_ch != 3 or num_out_ch != 3:
@@ -64,7 +66,7 @@ class RRDBNet(HipModule):
 
     def _engine_config(self):
         return dict(arch=_lib.ARCH_RRDBNET, scale=self.scale, n_feats=self.num_feat, n_blocks=self.num_block,
-                    grow_ch=self.num_grow_ch)
+                    grow_ch=self.num_grow_ch, growth_round8=self._srmi_growth_round8)
 
 
 def infer_model_type(model_path):

@@ -42,7 +42,7 @@ def test_state_dict_layout_matches_reference(golden_dir):
 
 def test_constructor_signatures_match_reference():
     def names(f):
-        return [p for p in inspect.signature(f).parameters if p not in ("self", "compute_dtype", "trunk_f32", "device")]
+        return [p for p in inspect.signature(f).parameters if p not in ("self", "compute_dtype", "trunk_f32", "device", "growth_round8")]
     assert names(realesrgan_model.RRDBNet.__init__) == ["num_in_ch", "num_out_ch", "num_feat", "num_block", "num_grow_ch", "scale"]
     assert names(edsr_model.EDSR.__init__) == ["n_resblocks", "n_feats", "scale", "rgb_range", "res_scale", "conv"]
     assert names(rcan_model.RCAN.__init__) == ["scale", "n_resgroups", "n_resblocks", "n_feats", "reduction", "res_scale", "rgb_range"]

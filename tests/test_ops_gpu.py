@@ -247,3 +247,21 @@ def test_f16_stores_saturate_instead_of_overflowing():
     assert torch.isfinite(out).all()
     assert float(out[0, 0].min()) == 65504.0 and float(out[0, 1].max()) == -65504.0
     assert float(out[0, 2].min()) == 40000.0 == float(out[0, 2].max())
+
+
+def test_conv_output_rounded_to_8_significant_bits():
+    """SRMI_TENSOR_ROUND8 on `out`: every stored f16 value is bfloat16-representable and equals the f32 result rounded
+    to bfloat16 (nearest even); the plain store of the same conv differs from it."""
+    n, h, w = 1, 25, 40
+    x = q(rnd("x", (n, 64, h, w), 1), _lib.F16)
+    wt = q(rnd("w", (32, 64, 3, 3), 2, 0.1), _lib.F16)
+    b = rnd("b", (32,), 3)
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), _lib.F16)
+    xp = ops.Planes.from_nchw(x, _lib.F16)
+    exact = ops.conv3x3(xp, pc, act=_lib.ACT_LRELU, out_dtype=_lib.F32).to_nchw().cpu()
+    plain = ops.conv3x3(xp, pc, act=_lib.ACT_LRELU).to_nchw().cpu()
+    got = ops.conv3x3(xp, pc, act=_lib.ACT_LRELU, out_round8=True).to_nchw().cpu()
+    want = exact.to(torch.bfloat16).to(torch.float16).to(torch.float32)
+    assert torch.equal(got, want)
+    assert torch.equal(got, got.to(torch.bfloat16).to(torch.float32))
+    assert not torch.equal(got, plain)
