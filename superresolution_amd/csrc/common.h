@@ -77,3 +77,6 @@ struct ConvParams {
 };
 
 }  // namespace srmi
+
+// conv3x3.hip: per-device kernel attributes of every instantiation (current device)
+int srmi_conv3x3_prepare_device();

@@ -33,8 +33,18 @@
 // 16-byte chunks (one 32x32x16 half MFMA, or four 32x32x2 f32 MFMAs) and in the epilogue casts.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "devutil.h"
+
+// Timing ablations, in-kernel stamps and alternative schedules are diagnostic builds (tools/build_variant.sh
+// passes -DSRMI_DIAG with them); the shipped library is built without any of them.
+#if !defined(SRMI_DIAG) && (defined(SRMI_ABL_NO_DMA) || defined(SRMI_ABL_NO_DMA_A) || defined(SRMI_ABL_NO_DMA_B) || \
+                            defined(SRMI_ABL_NO_LDS) || defined(SRMI_STAMPS) || defined(SRMI_BULK_ISSUE) ||          \
+                            defined(SRMI_SINGLE_FRAG) || defined(SRMI_NO_XCD_MAP) || defined(SRMI_CLOCK) || defined(SRMI_NW) || defined(SRMI_RING))
+#error "diagnostic kernel variants need -DSRMI_DIAG"
+#endif
 
 namespace srmi {
 
@@ -544,6 +554,13 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
     for (int j = 0; j < BPW; ++j) my_pieces += (wave + kNW * j < G::B_PIECES) ? 1 : 0;
     my_pieces = __builtin_amdgcn_readfirstlane(my_pieces);
 
+#ifdef SRMI_CLOCK
+    // diagnostic build: shader-clock and 100 MHz real-time counters at both ends of the workgroup's life,
+    // [workgroup][wave][4] = {cycles0, real0, cycles1, real1}; held clock = d(cycles) / d(real) * 100 MHz
+    unsigned long long* clock_buf = (unsigned long long*)p.tail_out;
+    const size_t clock_base = (((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kNW + wave) * 4;
+    const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     STAMP();
     issue(0, 0);
     if (tid < 32 * NB) ((float*)(smem + G::LDS_BYTES))[tid] = p.bias[ct * 32 * NB + tid];
@@ -770,22 +787,38 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
         epilogue<DT, MB, NB, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc, lds_bias, lds_red);
     }
     STAMP();
+#ifdef SRMI_CLOCK
+    if (clock_buf && lane == 0 && p.tail_mode == SRMI_TAIL_NONE) {
+        clock_buf[clock_base + 0] = clk_c0;
+        clock_buf[clock_base + 1] = clk_r0;
+        clock_buf[clock_base + 2] = __builtin_amdgcn_s_memtime();
+        clock_buf[clock_base + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 #endif
 }
 
 // ---- host launcher --------------------------------------------------------------------------------
+// The dynamic-LDS limit is a per-device attribute of the function: set once on every device used.  Setting
+// it twice is harmless, so concurrent first calls only need the bookkeeping itself to be atomic.
+template <int DT, int MB, int NB>
+static int configure() {
+    static std::atomic<unsigned long long> configured{0};
+    int dev = 0;
+    SRMI_HIP(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < 64;
+    if (!tracked || !(configured.load(std::memory_order_acquire) >> dev & 1ull)) {
+        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvGeom<MB, NB>::LDS_TOTAL));
+        if (tracked) configured.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    return 0;
+}
+
 template <int DT, int MB, int NB>
 static int launch(const ConvParams& p, hipStream_t stream) {
     constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL;
-    // the dynamic-LDS limit is a per-device attribute of the function: set it once on every device used
-    static bool configured[64] = {};
-    int dev = 0;
-    SRMI_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !configured[dev]) {
-        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0 && dev < 64) configured[dev] = true;
-    }
+    if (configure<DT, MB, NB>()) return -1;
     dim3 grid(p.tiles_x * p.tiles_y, p.cout / (32 * NB), p.n);
     hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB>), grid, dim3(64 * kNW), lds, stream, p);
     SRMI_HIP(hipGetLastError());
@@ -804,11 +837,23 @@ static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
     return launch<DT, 3, 2>(p, s);
 }
 
+template <int DT>
+static int configure_dt() {
+    return configure<DT, 2, 1>() || configure<DT, 3, 1>() || configure<DT, 4, 1>() || configure<DT, 2, 2>() ||
+           configure<DT, 3, 2>();
+}
+
 static int default_rows_per_wave() { return 3; }  // 12-row tiles: the fastest variant on every layer measured
 
 }  // namespace srmi
 
 using namespace srmi;
+
+// Sets the kernel attributes of every instantiation on the current device, so that later launches on it
+// (for instance under stream capture) consist of the launch alone.
+int srmi_conv3x3_prepare_device() {
+    return (configure_dt<SRMI_F16>() || configure_dt<SRMI_BF16>() || configure_dt<SRMI_F32>()) ? -1 : 0;
+}
 
 extern "C" int srmi_conv3x3_tiles(int h, int w, int rows_per_wave) {
     const int mb = rows_per_wave ? rows_per_wave : default_rows_per_wave();
@@ -868,8 +913,13 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.out = to_view(d->out); p.out2 = to_view(d->out2);
     p.chansum = d->chansum;
     p.tail_out = d->tail_out;
-#ifdef SRMI_STAMPS
-    if (d->tail_mode == SRMI_TAIL_NONE) p.tail_out = getenv("SRMI_STAMP_PTR") ? (void*)strtoull(getenv("SRMI_STAMP_PTR"), nullptr, 0) : nullptr;
+#if defined(SRMI_DIAG) && (defined(SRMI_STAMPS) || defined(SRMI_CLOCK))
+    if (d->tail_mode == SRMI_TAIL_NONE) {
+        p.tail_out = getenv("SRMI_STAMP_PTR") ? (void*)strtoull(getenv("SRMI_STAMP_PTR"), nullptr, 0) : nullptr;
+        // optional filter: only launches with this many input channels / outputs record
+        if (getenv("SRMI_STAMP_CIN") && atoi(getenv("SRMI_STAMP_CIN")) != d->cin) p.tail_out = nullptr;
+        if (getenv("SRMI_STAMP_COUT") && atoi(getenv("SRMI_STAMP_COUT")) != d->cout) p.tail_out = nullptr;
+    }
 #endif
     for (int i = 0; i < 9; ++i) p.tail_mat[i] = d->tail_mat[i];
     for (int i = 0; i < 3; ++i) p.tail_bias[i] = d->tail_bias[i];

@@ -5,5 +5,5 @@ set -e
 tag=$1; shift
 cd "$(dirname "$0")/../superresolution_amd/csrc"
 mkdir -p ../variants
-make -j8 BUILD=build_$tag OUT=../variants/libsrmi355_$tag.so EXTRA="$*" 2>&1 | grep -E "error|warning: v" || true
+make -j8 BUILD=build_$tag OUT=../variants/libsrmi355_$tag.so EXTRA="-DSRMI_DIAG $*" 2>&1 | grep -E "error|warning: v" || true
 ls -la ../variants/libsrmi355_$tag.so
