@@ -236,7 +236,10 @@ const char* srmi_model_key(const srmi_model_t* m, int i);
 /* Pack and upload the weights.  Fails if a key is missing (strict=True semantics). */
 int srmi_model_finalize(srmi_model_t* m);
 
-/* forward(x): f32 NCHW [n][3][h][w] -> f32 NCHW [n][3][h*scale][w*scale], device pointers.
+/* Calls on ONE model are serialised: each call is ordered behind the previous call on that model (an
+ * event wait on the caller's stream), whatever streams or host threads they come from, because they
+ * share the model's workspace.  Different models are independent.
+ * forward(x): f32 NCHW [n][3][h][w] -> f32 NCHW [n][3][h*scale][w*scale], device pointers.
  * EDSR/RCAN: 0..rgb_range domain including MeanShift; RRDBNet: [0,1], no clamp. */
 int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* out, int n, int h, int w,
                            void* hip_stream);
@@ -245,6 +248,25 @@ int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* out, int n, 
  * clamp(v + mean*range, 0, 255) (edsr.cpp:21-41,101-122). */
 int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
                           int round_mode, void* hip_stream);
+/* Allocates, ahead of the first call, everything a later srmi_model_forward_* of up to (n, h, w) needs
+ * (workspace, lane streams, events), so that the first inference does not pay for it; the runners call
+ * it from <m>_init, as the reference builds its executor and staging buffers in <m>_init
+ * (realesrgan.cpp:137-190). */
+int srmi_model_reserve(srmi_model_t* m, int n, int h, int w);
+/*
+ * srmi_model_forward_u8 for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs, outputs and
+ * results as srmi_model_forward_u8, but the activations live in a static array of
+ * srmi_static_workspace_bytes() (64 MiB) that is part of the library's code object on every GPU, the
+ * work runs on the caller's stream alone (no internal lanes), and the call creates no stream, event or
+ * allocation.  Inputs whose workspace exceeds the array (e.g. RRDBNet x4 beyond about 100x100 pixels
+ * per image) fail with a message naming both sizes.  All models on one GPU share that GPU's array:
+ * calls that overlap in time on one GPU (different streams or threads) race; calls on one stream, or
+ * ordered by events, are safe.  Nothing in the array has to start at zero.
+ */
+int srmi_model_forward_u8_noalloc(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
+                                  int round_mode, void* hip_stream);
+size_t srmi_static_workspace_bytes(void);
 /* u8 runner path of a Core (no-MeanShift) EDSR / RCAN model: subtract shift[c] (= mean*range)
  * before the first conv and add it back after the last one (edsr.cpp:36-37,116).  No effect on
  * full models (their MeanShift tensors are used) or RRDBNet. */

@@ -24,10 +24,18 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "common.h"
+
+// Workspace of srmi_model_forward_u8_noalloc: one array per GPU, part of the library's code object, so
+// the entry point never allocates.  Host code must not pass the array's name to a kernel or a memset
+// (on the host the name is only a stand-in for the symbol): it uses the per-device address that
+// hipGetSymbolAddress returned at set-up (static_workspace() below).
+#define SRMI_STATIC_WS_BYTES (64ull << 20)
+static __device__ __align__(256) unsigned char scratch[SRMI_STATIC_WS_BYTES];
 
 namespace srmi {
 
@@ -93,6 +101,14 @@ struct srmi_model {
     hipStream_t lane_stream[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
+    // Calls on one model share its workspace and lanes: `call_mutex` serialises their host side and every
+    // call waits for `last_done` (recorded on the previous caller's stream), so calls issued from
+    // different streams or threads run one after the other on the device instead of overwriting each
+    // other's activations.
+    std::mutex call_mutex;
+    hipEvent_t last_done = nullptr;
+    bool has_last_done = false;
+    char* static_ws = nullptr;  // this device's copy of `scratch` (resolved in srmi_model_finalize)
 
     int cdt() const { return d.dtype; }
     int tdt() const { return (d.dtype == SRMI_F32 || d.trunk_f32) ? SRMI_F32 : d.dtype; }  // trunk dtype
@@ -206,8 +222,11 @@ static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
     // RRDBNet, where four of five convs of a dense block have 32 outputs anyway, that also pays for
     // the 64-output convs; EDSR and RCAN (64/256 outputs throughout) run faster on 64-wide tiles,
     // which fetch the pixel patch once per 64 outputs.
-    cw.cout_tile = (cw.cout <= 32 || m->d.arch == SRMI_ARCH_RRDBNET) ? 32 : 64;
-    if (getenv("SRMI_COUT_TILE")) cw.cout_tile = atoi(getenv("SRMI_COUT_TILE")) == 32 || cw.cout <= 32 ? 32 : 64;  // diagnostic
+    // (output counts that are not a multiple of 64, e.g. n_feats 96 or 32*9 for scale 3, also take 32)
+    cw.cout_tile = (cw.cout <= 32 || cw.cout % 64 || m->d.arch == SRMI_ARCH_RRDBNET) ? 32 : 64;
+#ifdef SRMI_DIAG  // diagnostic builds only: the shipped library takes no tiling from the environment
+    if (getenv("SRMI_COUT_TILE")) cw.cout_tile = atoi(getenv("SRMI_COUT_TILE")) == 32 || cw.cout <= 32 ? 32 : 64;
+#endif
     cw.ps_r = ps_r;
     std::vector<float> rounded;
     const float* wsrc = w.data.data();
@@ -577,35 +596,106 @@ static int run_plan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
     SRMI_FAIL("unknown architecture %d", m->d.arch);
 }
 
-static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t stream) {
-    if (!m) SRMI_FAIL("forward: null model");
-    if (!m->finalized) SRMI_FAIL("forward: srmi_model_finalize has not been called");
-    if (!io.in || !io.out) SRMI_FAIL("forward: null input or output pointer");
-    if (n <= 0 || h <= 0 || w <= 0) SRMI_FAIL("forward: bad shape n=%d h=%d w=%d", n, h, w);
-    SRMI_HIP(hipSetDevice(m->d.device));
+// Address of this device's copy of `scratch` (the device must be current).  Every GPU holds its own copy
+// at its own address, so the pointer is looked up once per device and kept.
+static int static_workspace(int device, char** out) {
+    static std::mutex mu;
+    static char* ptr[64] = {};
+    if (device < 0 || device >= 64) SRMI_FAIL("static workspace: device %d out of range", device);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[device]) {
+        void* p = nullptr;
+        SRMI_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) SRMI_FAIL("static workspace: hipGetSymbolAddress returned a null address");
+        ptr[device] = (char*)p;
+    }
+    *out = ptr[device];
+    return 0;
+}
+
+// RAII: make `device` current for a call and restore the caller's device afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        SRMI_HIP(hipGetDevice(&prev));
+        if (prev != device) {
+            SRMI_HIP(hipSetDevice(device));
+            switched = true;
+        }
+        return 0;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// Largest workspace a forward of (n, h, w) needs with the model's current sweep and lane settings.
+static int plan_bytes(srmi_model* m, int n, int h, int w, int max_lanes, int* ns_out, int* lanes_out, size_t* lane_bytes) {
     const int ns = n < m->sweep ? n : m->sweep;
     Arena probe;
     probe.ns = ns;
+    IoSpec io;
+    memset(&io, 0, sizeof(io));
     if (run_plan(m, probe, nullptr, &io, h, w)) return -1;
     const int chunks = (n + ns - 1) / ns;
-    const int lanes = chunks < m->lanes ? chunks : m->lanes;
-    const size_t lane_bytes = (probe.off + 255) & ~(size_t)255;
-    if (lane_bytes * lanes > m->ws_bytes) {
-        // growing the workspace is the only allocation on the forward path; wait for work that
-        // may still use the old buffer first
+    *ns_out = ns;
+    *lanes_out = chunks < max_lanes ? chunks : max_lanes;
+    *lane_bytes = (probe.off + 255) & ~(size_t)255;
+    return 0;
+}
+
+// Grows the model's own workspace and creates its lane streams / events (the only allocations of the
+// forward path; srmi_model_reserve runs them ahead of time).  Caller holds call_mutex.
+static int ensure_resources(srmi_model* m, size_t bytes, int lanes) {
+    if (bytes > m->ws_bytes) {
+        // wait for work that may still use the old buffer first
         SRMI_HIP(hipDeviceSynchronize());
         if (m->ws) SRMI_HIP(hipFree(m->ws));
         m->ws = nullptr;
         m->ws_bytes = 0;
-        SRMI_HIP(hipMalloc((void**)&m->ws, lane_bytes * lanes));
-        m->ws_bytes = lane_bytes * lanes;
+        SRMI_HIP(hipMalloc((void**)&m->ws, bytes));
+        m->ws_bytes = bytes;
     }
+    if (!m->last_done) SRMI_HIP(hipEventCreateWithFlags(&m->last_done, hipEventDisableTiming));
     if (lanes > 1) {
         if (!m->fork) SRMI_HIP(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
         for (int l = 0; l < lanes; ++l) {
             if (!m->lane_stream[l]) SRMI_HIP(hipStreamCreateWithFlags(&m->lane_stream[l], hipStreamNonBlocking));
             if (!m->lane_done[l]) SRMI_HIP(hipEventCreateWithFlags(&m->lane_done[l], hipEventDisableTiming));
         }
+    }
+    return 0;
+}
+
+// static_ws: run in the per-device static array on the caller's stream only, without any allocation,
+// stream or event creation (srmi_model_forward_u8_noalloc); otherwise in the model's own workspace.
+static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t stream, bool static_ws = false) {
+    if (!m) SRMI_FAIL("forward: null model");
+    if (!m->finalized) SRMI_FAIL("forward: srmi_model_finalize has not been called");
+    if (!io.in || !io.out) SRMI_FAIL("forward: null input or output pointer");
+    if (n <= 0 || h <= 0 || w <= 0) SRMI_FAIL("forward: bad shape n=%d h=%d w=%d", n, h, w);
+    DeviceGuard guard;
+    if (guard.enter(m->d.device)) return -1;
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    int ns = 1, lanes = 1;
+    size_t lane_bytes = 0;
+    if (plan_bytes(m, n, h, w, static_ws ? 1 : m->lanes, &ns, &lanes, &lane_bytes)) return -1;
+    char* ws = nullptr;
+    if (static_ws) {
+        if (!m->static_ws) SRMI_FAIL("forward: the static workspace of device %d was not resolved", m->d.device);
+        if (lane_bytes > SRMI_STATIC_WS_BYTES)
+            SRMI_FAIL("srmi_model_forward_u8_noalloc: a %dx%d input needs %zu bytes of workspace, the static workspace "
+                      "holds %llu (use srmi_model_forward_u8, or smaller tiles)", w, h, lane_bytes,
+                      (unsigned long long)SRMI_STATIC_WS_BYTES);
+        ws = m->static_ws;
+    } else {
+        if (ensure_resources(m, lane_bytes * lanes, lanes)) return -1;
+        ws = m->ws;
+        // order this call behind the previous one on this model, whatever stream that ran on
+        if (m->has_last_done) SRMI_HIP(hipStreamWaitEvent(stream, m->last_done, 0));
+    }
+    if (lanes > 1) {
         SRMI_HIP(hipEventRecord(m->fork, stream));
         for (int l = 0; l < lanes; ++l) SRMI_HIP(hipStreamWaitEvent(m->lane_stream[l], m->fork, 0));
     }
@@ -622,7 +712,7 @@ static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t st
         ex.stream = lanes > 1 ? m->lane_stream[lane] : stream;
         ex.ns = (n - i) < ns ? (n - i) : ns;
         Arena A;
-        A.base = m->ws + (size_t)lane * lane_bytes;
+        A.base = ws + (size_t)lane * lane_bytes;
         A.ns = ns;
         io.in = in0 + (size_t)i * in_img;
         io.out = out0 + (size_t)i * out_img;
@@ -634,6 +724,10 @@ static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t st
             SRMI_HIP(hipEventRecord(m->lane_done[l], m->lane_stream[l]));
             SRMI_HIP(hipStreamWaitEvent(stream, m->lane_done[l], 0));
         }
+    }
+    if (!static_ws) {
+        SRMI_HIP(hipEventRecord(m->last_done, stream));
+        m->has_last_done = true;
     }
     return rc;
 }
@@ -675,8 +769,10 @@ extern "C" int srmi_model_create(const srmi_model_desc_t* desc, srmi_model_t** o
     if (m->d.dtype == SRMI_F32) m->d.trunk_f32 = 0;
     for (int i = 0; i < 9; ++i) m->sub_mat[i] = m->add_mat[i] = kIdentity[i];
     for (int i = 0; i < 3; ++i) m->sub_bias[i] = m->add_bias[i] = 0.f;
+#ifdef SRMI_DIAG
     const char* e = getenv("SRMI_ROWS_PER_WAVE");
     if (e && atoi(e) >= 2 && atoi(e) <= 4) m->mb_override = atoi(e);
+#endif
     build_keys(m);
     *out = m;
     return 0;
@@ -693,6 +789,7 @@ extern "C" void srmi_model_destroy(srmi_model_t* m) {
         if (m->lane_stream[l]) (void)hipStreamDestroy(m->lane_stream[l]);
     }
     if (m->fork) (void)hipEventDestroy(m->fork);
+    if (m->last_done) (void)hipEventDestroy(m->last_done);
     delete m;
 }
 
@@ -779,6 +876,10 @@ extern "C" int srmi_model_finalize(srmi_model_t* m) {
                 }
         }
     }
+    // set-up for the allocation-free entry point: this device's address of the static workspace, and
+    // the per-device kernel attributes, so that nothing but launches is left for the call itself
+    if (static_workspace(d.device, &m->static_ws)) return -1;
+    if (srmi_conv3x3_prepare_device()) return -1;
     m->finalized = true;
     return 0;
 }
@@ -802,11 +903,9 @@ extern "C" int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* o
     return forward(m, io, n, h, w, (hipStream_t)hip_stream);
 }
 
-extern "C" int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
-                                     int round_mode, void* hip_stream) {
-    if (!m) SRMI_FAIL("srmi_model_forward_u8: null model");
-    if (round_mode < 0 || round_mode > 2) SRMI_FAIL("srmi_model_forward_u8: bad round_mode %d", round_mode);
-    IoSpec io;
+// Pre/post-processing of the runners' u8 path for this model.
+static void u8_io(const srmi_model* m, const uint8_t* in, uint8_t* out, int round_mode, IoSpec* iop) {
+    IoSpec& io = *iop;
     memset(&io, 0, sizeof(io));
     io.in_kind = SRMI_IN_U8_NHWC;
     io.in = in;
@@ -833,7 +932,39 @@ extern "C" int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t
         }
         io.lo = 0.f; io.hi = 255.f; io.scale = 1.f;
     }
+}
+
+extern "C" int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
+                                     int round_mode, void* hip_stream) {
+    if (!m) SRMI_FAIL("srmi_model_forward_u8: null model");
+    if (round_mode < 0 || round_mode > 2) SRMI_FAIL("srmi_model_forward_u8: bad round_mode %d", round_mode);
+    IoSpec io;
+    u8_io(m, in, out, round_mode, &io);
     return forward(m, io, n, h, w, (hipStream_t)hip_stream);
+}
+
+extern "C" int srmi_model_forward_u8_noalloc(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
+                                             int round_mode, void* hip_stream) {
+    if (!m) SRMI_FAIL("srmi_model_forward_u8_noalloc: null model");
+    if (round_mode < 0 || round_mode > 2) SRMI_FAIL("srmi_model_forward_u8_noalloc: bad round_mode %d", round_mode);
+    IoSpec io;
+    u8_io(m, in, out, round_mode, &io);
+    return forward(m, io, n, h, w, (hipStream_t)hip_stream, /*static_ws=*/true);
+}
+
+extern "C" size_t srmi_static_workspace_bytes(void) { return (size_t)SRMI_STATIC_WS_BYTES; }
+
+extern "C" int srmi_model_reserve(srmi_model_t* m, int n, int h, int w) {
+    if (!m) SRMI_FAIL("srmi_model_reserve: null model");
+    if (!m->finalized) SRMI_FAIL("srmi_model_reserve: srmi_model_finalize has not been called");
+    if (n <= 0 || h <= 0 || w <= 0) SRMI_FAIL("srmi_model_reserve: bad shape n=%d h=%d w=%d", n, h, w);
+    DeviceGuard guard;
+    if (guard.enter(m->d.device)) return -1;
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    int ns = 1, lanes = 1;
+    size_t lane_bytes = 0;
+    if (plan_bytes(m, n, h, w, m->lanes, &ns, &lanes, &lane_bytes)) return -1;
+    return ensure_resources(m, lane_bytes * lanes, lanes);
 }
 
 // Core (no-MeanShift) models on the u8 runner path: p - shift before the first conv, + shift after
