@@ -253,6 +253,15 @@ int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int 
  * it from <m>_init, as the reference builds its executor and staging buffers in <m>_init
  * (realesrgan.cpp:137-190). */
 int srmi_model_reserve(srmi_model_t* m, int n, int h, int w);
+/* Frames in HOST memory -> frames in HOST memory (u8 NHWC both sides), synchronous: the shape of the
+ * reference runners' API (realesrgan.cpp:217-257: host image in, host image out).  Frame i runs on internal
+ * lane i % lanes: copy into the lane's pinned staging buffer, H2D, network and D2H on the lane's
+ * stream; the calling thread copies finished frames out while the GPU works on the other lanes, so
+ * PCIe transfers and host copies overlap compute.  srmi_model_reserve_host allocates the staging ahead
+ * of time. */
+int srmi_model_forward_u8_host(srmi_model_t* m, const uint8_t* host_in, uint8_t* host_out, int n, int h, int w,
+                               int round_mode);
+int srmi_model_reserve_host(srmi_model_t* m, int n, int h, int w);
 /*
  * srmi_model_forward_u8 for callers that cannot allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs, outputs and

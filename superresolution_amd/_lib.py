@@ -72,7 +72,8 @@ EXPORTS = [
     "srmi_model_create", "srmi_model_destroy", "srmi_model_set_tensor", "srmi_model_num_keys",
     "srmi_model_key", "srmi_model_finalize", "srmi_model_forward_f32", "srmi_model_forward_u8",
     "srmi_model_workspace_bytes", "srmi_model_set_sweep", "srmi_model_set_lanes", "srmi_model_set_growth_round8", "srmi_model_flops", "srmi_model_set_rgb_shift",
-    "srmi_model_reserve", "srmi_model_forward_u8_noalloc", "srmi_static_workspace_bytes",
+    "srmi_model_reserve", "srmi_model_forward_u8_host", "srmi_model_reserve_host",
+    "srmi_model_forward_u8_noalloc", "srmi_static_workspace_bytes",
     "edsr_init", "edsr_release", "edsr_inference", "edsr_inference_ex",
     "rcan_init", "rcan_release", "rcan_inference", "rcan_inference_ex",
     "realesrgan_init", "realesrgan_release", "realesrgan_inference", "realesrgan_inference_ex",
@@ -131,6 +132,8 @@ def lib():
                                             C.c_int, C.c_int, C.c_void_p]
         L.srmi_model_forward_u8_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                     C.c_int, C.c_int, C.c_void_p]
+        L.srmi_model_forward_u8_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.srmi_model_reserve_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.srmi_model_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.srmi_static_workspace_bytes.argtypes = []
         L.srmi_static_workspace_bytes.restype = C.c_size_t

@@ -78,5 +78,9 @@ struct ConvParams {
 
 }  // namespace srmi
 
+// runners.cpp: weight-file loader and device choice shared by the runners and the executor
+int srmi_pick_device(int* device);
+int srmi_load_weight_file(const char* path, int want_arch, int device, srmi_model_t** out, srmi_model_desc_t* desc_out);
+
 // conv3x3.hip: per-device kernel attributes of every instantiation (current device)
 int srmi_conv3x3_prepare_device();

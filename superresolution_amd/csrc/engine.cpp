@@ -110,6 +110,14 @@ struct srmi_model {
     bool has_last_done = false;
     char* static_ws = nullptr;  // this device's copy of `scratch` (resolved in srmi_model_finalize)
 
+    // Host-buffer path (srmi_model_forward_u8_host): one slot per lane = pinned staging + device images
+    struct HostSlot {
+        uint8_t *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        hipEvent_t done = nullptr;
+    };
+    HostSlot slot[kMaxLanes];
+
     int cdt() const { return d.dtype; }
     int tdt() const { return (d.dtype == SRMI_F32 || d.trunk_f32) ? SRMI_F32 : d.dtype; }  // trunk dtype
     bool split_trunk() const { return tdt() != cdt(); }
@@ -647,7 +655,7 @@ static int plan_bytes(srmi_model* m, int n, int h, int w, int max_lanes, int* ns
 
 // Grows the model's own workspace and creates its lane streams / events (the only allocations of the
 // forward path; srmi_model_reserve runs them ahead of time).  Caller holds call_mutex.
-static int ensure_resources(srmi_model* m, size_t bytes, int lanes) {
+static int ensure_resources(srmi_model* m, size_t bytes, int lanes, bool lane_streams_always = false) {
     if (bytes > m->ws_bytes) {
         // wait for work that may still use the old buffer first
         SRMI_HIP(hipDeviceSynchronize());
@@ -658,7 +666,7 @@ static int ensure_resources(srmi_model* m, size_t bytes, int lanes) {
         m->ws_bytes = bytes;
     }
     if (!m->last_done) SRMI_HIP(hipEventCreateWithFlags(&m->last_done, hipEventDisableTiming));
-    if (lanes > 1) {
+    if (lanes > 1 || lane_streams_always) {
         if (!m->fork) SRMI_HIP(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
         for (int l = 0; l < lanes; ++l) {
             if (!m->lane_stream[l]) SRMI_HIP(hipStreamCreateWithFlags(&m->lane_stream[l], hipStreamNonBlocking));
@@ -732,6 +740,136 @@ static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t st
     return rc;
 }
 
+// Pre/post-processing of the runners' u8 path for this model.
+static void u8_io(const srmi_model* m, const uint8_t* in, uint8_t* out, int round_mode, IoSpec* iop) {
+    IoSpec& io = *iop;
+    memset(&io, 0, sizeof(io));
+    io.in_kind = SRMI_IN_U8_NHWC;
+    io.in = in;
+    io.tail_mode = SRMI_TAIL_U8_NHWC;
+    io.out = out;
+    io.round = round_mode;
+    memcpy(io.pre_mat, kIdentity, sizeof(io.pre_mat));
+    memcpy(io.post_mat, kIdentity, sizeof(io.post_mat));
+    if (m->d.arch == SRMI_ARCH_RRDBNET) {
+        // realesrgan.cpp:35,44 (p * (1/255)) and :124-126 (clamp(v,0,1)*255)
+        const float s = 1.0f / 255.0f;
+        io.pre_mat[0] = io.pre_mat[4] = io.pre_mat[8] = s;
+        io.lo = 0.f; io.hi = 1.f; io.scale = 255.f;
+    } else {
+        // edsr.cpp:36-37 (p - mean*range), :116-118 (clamp(v + mean*range, 0, 255)).  With a full
+        // model the shift comes from the checkpoint's MeanShift tensors, with a core model the
+        // caller's tensors are used as they are (identity, no shift).
+        if (m->d.with_meanshift) {
+            memcpy(io.pre_mat, m->sub_mat, sizeof(io.pre_mat));
+            memcpy(io.post_mat, m->add_mat, sizeof(io.post_mat));
+            for (int i = 0; i < 3; ++i) { io.pre_bias[i] = m->sub_bias[i]; io.post_bias[i] = m->add_bias[i]; }
+        } else if (m->has_core_shift) {
+            for (int i = 0; i < 3; ++i) { io.pre_bias[i] = -m->core_shift[i]; io.post_bias[i] = m->core_shift[i]; }
+        }
+        io.lo = 0.f; io.hi = 255.f; io.scale = 1.f;
+    }
+}
+
+// ---- host-buffer path ----------------------------------------------------------------------------
+static int ensure_host_slots(srmi_model* m, int slots, size_t in_bytes, size_t out_bytes) {
+    for (int l = 0; l < slots; ++l) {
+        auto& s = m->slot[l];
+        if (!s.done) SRMI_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        if (in_bytes > s.in_cap) {
+            if (s.pin_in) SRMI_HIP(hipHostFree(s.pin_in));
+            if (s.dev_in) SRMI_HIP(hipFree(s.dev_in));
+            s.pin_in = s.dev_in = nullptr;
+            s.in_cap = 0;
+            SRMI_HIP(hipHostMalloc((void**)&s.pin_in, in_bytes, hipHostMallocDefault));
+            SRMI_HIP(hipMalloc((void**)&s.dev_in, in_bytes));
+            s.in_cap = in_bytes;
+        }
+        if (out_bytes > s.out_cap) {
+            if (s.pin_out) SRMI_HIP(hipHostFree(s.pin_out));
+            if (s.dev_out) SRMI_HIP(hipFree(s.dev_out));
+            s.pin_out = s.dev_out = nullptr;
+            s.out_cap = 0;
+            SRMI_HIP(hipHostMalloc((void**)&s.pin_out, out_bytes, hipHostMallocDefault));
+            SRMI_HIP(hipMalloc((void**)&s.dev_out, out_bytes));
+            s.out_cap = out_bytes;
+        }
+    }
+    return 0;
+}
+
+static void free_host_slots(srmi_model* m) {
+    for (auto& s : m->slot) {
+        if (s.pin_in) (void)hipHostFree(s.pin_in);
+        if (s.pin_out) (void)hipHostFree(s.pin_out);
+        if (s.dev_in) (void)hipFree(s.dev_in);
+        if (s.dev_out) (void)hipFree(s.dev_out);
+        if (s.done) (void)hipEventDestroy(s.done);
+        s = srmi_model::HostSlot();
+    }
+}
+
+// Frames in host memory -> frames in host memory, synchronous.  Frame i runs on lane i % lanes:
+// memcpy into the lane's pinned buffer, then on the lane's stream H2D -> network -> D2H into the lane's
+// pinned output; while the GPU works on the other lanes' frames the calling thread copies finished
+// frames out of the pinned buffers.  Copies therefore overlap compute on both sides.
+static int forward_u8_host(srmi_model* m, const uint8_t* in, uint8_t* out, int n, int h, int w, int round_mode) {
+    if (!m->finalized) SRMI_FAIL("srmi_model_forward_u8_host: srmi_model_finalize has not been called");
+    if (!in || !out) SRMI_FAIL("srmi_model_forward_u8_host: null input or output pointer");
+    if (n <= 0 || h <= 0 || w <= 0) SRMI_FAIL("srmi_model_forward_u8_host: bad shape n=%d h=%d w=%d", n, h, w);
+    DeviceGuard guard;
+    if (guard.enter(m->d.device)) return -1;
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    const int lanes = n < m->lanes ? n : m->lanes;
+    // one frame per sweep on this path: a lane holds exactly one frame
+    Arena probe;
+    probe.ns = 1;
+    IoSpec io;
+    u8_io(m, nullptr, nullptr, round_mode, &io);
+    if (run_plan(m, probe, nullptr, &io, h, w)) return -1;
+    const size_t lane_bytes = (probe.off + 255) & ~(size_t)255;
+    if (ensure_resources(m, lane_bytes * lanes, lanes, true)) return -1;
+    const size_t in_bytes = (size_t)h * w * 3;
+    const size_t out_bytes = in_bytes * m->d.scale * m->d.scale;
+    if (ensure_host_slots(m, lanes, in_bytes, out_bytes)) return -1;
+    if (m->has_last_done) SRMI_HIP(hipEventSynchronize(m->last_done));
+    int rc = 0;
+    auto drain = [&](int frame) -> int {
+        auto& s = m->slot[frame % lanes];
+        SRMI_HIP(hipEventSynchronize(s.done));
+        memcpy(out + (size_t)frame * out_bytes, s.pin_out, out_bytes);
+        return 0;
+    };
+    int issued = 0;
+    for (int i = 0; i < n && !rc; ++i) {
+        const int l = i % lanes;
+        auto& s = m->slot[l];
+        if (i >= lanes && drain(i - lanes)) { rc = -1; break; }
+        memcpy(s.pin_in, in + (size_t)i * in_bytes, in_bytes);
+        hipStream_t st = m->lane_stream[l];
+        SRMI_HIP(hipMemcpyAsync(s.dev_in, s.pin_in, in_bytes, hipMemcpyHostToDevice, st));
+        Exec ex;
+        ex.m = m;
+        ex.stream = st;
+        ex.ns = 1;
+        Arena A;
+        A.base = m->ws + (size_t)l * lane_bytes;
+        A.ns = 1;
+        io.in = s.dev_in;
+        io.out = s.dev_out;
+        rc = run_plan(m, A, &ex, &io, h, w);
+        if (rc) break;
+        SRMI_HIP(hipMemcpyAsync(s.pin_out, s.dev_out, out_bytes, hipMemcpyDeviceToHost, st));
+        SRMI_HIP(hipEventRecord(s.done, st));
+        issued = i + 1;
+    }
+    // frames issued - lanes .. issued - 1 are still in their slots
+    for (int f = issued > lanes ? issued - lanes : 0; f < issued; ++f)
+        if (drain(f)) rc = -1;
+    if (rc) (void)hipDeviceSynchronize();
+    return rc;
+}
+
 }  // namespace srmi
 
 // ---------------------------------------------------------------------------------------------------
@@ -790,6 +928,7 @@ extern "C" void srmi_model_destroy(srmi_model_t* m) {
     }
     if (m->fork) (void)hipEventDestroy(m->fork);
     if (m->last_done) (void)hipEventDestroy(m->last_done);
+    free_host_slots(m);
     delete m;
 }
 
@@ -903,37 +1042,6 @@ extern "C" int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* o
     return forward(m, io, n, h, w, (hipStream_t)hip_stream);
 }
 
-// Pre/post-processing of the runners' u8 path for this model.
-static void u8_io(const srmi_model* m, const uint8_t* in, uint8_t* out, int round_mode, IoSpec* iop) {
-    IoSpec& io = *iop;
-    memset(&io, 0, sizeof(io));
-    io.in_kind = SRMI_IN_U8_NHWC;
-    io.in = in;
-    io.tail_mode = SRMI_TAIL_U8_NHWC;
-    io.out = out;
-    io.round = round_mode;
-    memcpy(io.pre_mat, kIdentity, sizeof(io.pre_mat));
-    memcpy(io.post_mat, kIdentity, sizeof(io.post_mat));
-    if (m->d.arch == SRMI_ARCH_RRDBNET) {
-        // realesrgan.cpp:35,44 (p * (1/255)) and :124-126 (clamp(v,0,1)*255)
-        const float s = 1.0f / 255.0f;
-        io.pre_mat[0] = io.pre_mat[4] = io.pre_mat[8] = s;
-        io.lo = 0.f; io.hi = 1.f; io.scale = 255.f;
-    } else {
-        // edsr.cpp:36-37 (p - mean*range), :116-118 (clamp(v + mean*range, 0, 255)).  With a full
-        // model the shift comes from the checkpoint's MeanShift tensors, with a core model the
-        // caller's tensors are used as they are (identity, no shift).
-        if (m->d.with_meanshift) {
-            memcpy(io.pre_mat, m->sub_mat, sizeof(io.pre_mat));
-            memcpy(io.post_mat, m->add_mat, sizeof(io.post_mat));
-            for (int i = 0; i < 3; ++i) { io.pre_bias[i] = m->sub_bias[i]; io.post_bias[i] = m->add_bias[i]; }
-        } else if (m->has_core_shift) {
-            for (int i = 0; i < 3; ++i) { io.pre_bias[i] = -m->core_shift[i]; io.post_bias[i] = m->core_shift[i]; }
-        }
-        io.lo = 0.f; io.hi = 255.f; io.scale = 1.f;
-    }
-}
-
 extern "C" int srmi_model_forward_u8(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
                                      int round_mode, void* hip_stream) {
     if (!m) SRMI_FAIL("srmi_model_forward_u8: null model");
@@ -950,6 +1058,32 @@ extern "C" int srmi_model_forward_u8_noalloc(srmi_model_t* m, const uint8_t* in,
     IoSpec io;
     u8_io(m, in, out, round_mode, &io);
     return forward(m, io, n, h, w, (hipStream_t)hip_stream, /*static_ws=*/true);
+}
+
+extern "C" int srmi_model_forward_u8_host(srmi_model_t* m, const uint8_t* host_in, uint8_t* host_out, int n, int h, int w,
+                                          int round_mode) {
+    if (!m) SRMI_FAIL("srmi_model_forward_u8_host: null model");
+    if (round_mode < 0 || round_mode > 2) SRMI_FAIL("srmi_model_forward_u8_host: bad round_mode %d", round_mode);
+    return forward_u8_host(m, host_in, host_out, n, h, w, round_mode);
+}
+
+extern "C" int srmi_model_reserve_host(srmi_model_t* m, int n, int h, int w) {
+    if (!m) SRMI_FAIL("srmi_model_reserve_host: null model");
+    if (!m->finalized) SRMI_FAIL("srmi_model_reserve_host: srmi_model_finalize has not been called");
+    if (n <= 0 || h <= 0 || w <= 0) SRMI_FAIL("srmi_model_reserve_host: bad shape n=%d h=%d w=%d", n, h, w);
+    DeviceGuard guard;
+    if (guard.enter(m->d.device)) return -1;
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    const int lanes = n < m->lanes ? n : m->lanes;
+    Arena probe;
+    probe.ns = 1;
+    IoSpec io;
+    memset(&io, 0, sizeof(io));
+    if (run_plan(m, probe, nullptr, &io, h, w)) return -1;
+    const size_t lane_bytes = (probe.off + 255) & ~(size_t)255;
+    if (ensure_resources(m, lane_bytes * lanes, lanes, true)) return -1;
+    const size_t in_bytes = (size_t)h * w * 3;
+    return ensure_host_slots(m, lanes, in_bytes, in_bytes * m->d.scale * m->d.scale);
 }
 
 extern "C" size_t srmi_static_workspace_bytes(void) { return (size_t)SRMI_STATIC_WS_BYTES; }

@@ -17,7 +17,6 @@
 #include "../../include/realesrgan.h"
 #include "common.h"
 
-extern "C" int srmi_model_set_rgb_shift(srmi_model_t* m, const float* mean_times_range);
 
 namespace srmi {
 
@@ -26,8 +25,36 @@ struct Runner {
     hipStream_t stream = nullptr;
     uint8_t *d_in = nullptr, *d_resized = nullptr, *d_out = nullptr;
     size_t in_cap = 0;
-    int in_w = 0, in_h = 0, scale = 0;
+    int in_w = 0, in_h = 0, scale = 0, device = 0;
 };
+
+// Input of another size: upload, bilinear resize on the device (edsr.cpp:46-94), network, download.
+static int runner_run_resized(Runner* r, const unsigned char* rgb, int w, int h, unsigned char* host, size_t out_bytes) {
+    int prev = 0;
+    SRMI_HIP(hipGetDevice(&prev));
+    SRMI_HIP(hipSetDevice(r->device));
+    int rc = -1;
+    do {
+        const size_t in_bytes = (size_t)w * h * 3;
+        if (in_bytes > r->in_cap) {
+            if (r->d_in && hipFree(r->d_in) != hipSuccess) break;
+            r->d_in = nullptr; r->in_cap = 0;
+            if (hipMalloc((void**)&r->d_in, in_bytes) != hipSuccess) { set_error("runner: cannot allocate the input image on the device"); break; }
+            r->in_cap = in_bytes;
+        }
+        if (hipMemcpyAsync(r->d_in, rgb, in_bytes, hipMemcpyHostToDevice, r->stream) != hipSuccess) { set_error("runner: host -> device copy failed"); break; }
+        if (srmi_resize_bilinear_u8(r->d_in, w, h, r->d_resized, r->in_w, r->in_h, r->stream)) break;
+        if (srmi_model_forward_u8(r->model, r->d_resized, r->d_out, 1, r->in_h, r->in_w, SRMI_ROUND_HALF_UP, r->stream)) break;
+        if (hipMemcpyAsync(host, r->d_out, out_bytes, hipMemcpyDeviceToHost, r->stream) != hipSuccess ||
+            hipStreamSynchronize(r->stream) != hipSuccess) {
+            set_error("runner: device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        rc = 0;
+    } while (0);
+    (void)hipSetDevice(prev);
+    return rc;
+}
 
 static int env_dtype() {
     const char* e = getenv("SRMI_DTYPE");
@@ -39,20 +66,15 @@ static int env_dtype() {
 
 static bool read_exact(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
 
-// Loads a weight file into a new model; `want_arch` guards against feeding e.g. an EDSR file to
-// rcan_init.
-static int load_model(const char* path, int want_arch, srmi_model_t** out, srmi_model_desc_t* desc_out) {
-    FILE* f = fopen(path, "rb");
-    if (!f) SRMI_FAIL("cannot open weight file %s", path);
+static int load_model_body(FILE* f, long file_size, const char* path, int want_arch, int device, srmi_model_t** out,
+                           srmi_model_desc_t* desc_out) {
     char magic[8];
     int32_t hdr[8];
     float res_scale;
     int32_t nt;
     if (!read_exact(f, magic, 8) || memcmp(magic, "SRMIW001", 8) || !read_exact(f, hdr, sizeof(hdr)) ||
-        !read_exact(f, &res_scale, 4) || !read_exact(f, &nt, 4)) {
-        fclose(f);
+        !read_exact(f, &res_scale, 4) || !read_exact(f, &nt, 4))
         SRMI_FAIL("%s is not an SRMIW001 weight file", path);
-    }
     srmi_model_desc_t d;
     memset(&d, 0, sizeof(d));
     d.arch = hdr[0]; d.scale = hdr[1]; d.n_feats = hdr[2]; d.n_blocks = hdr[3];
@@ -60,57 +82,118 @@ static int load_model(const char* path, int want_arch, srmi_model_t** out, srmi_
     d.res_scale = res_scale;
     d.dtype = env_dtype();
     d.trunk_f32 = 1;
-    d.device = 0;
-    if (d.arch != want_arch) {
-        fclose(f);
-        SRMI_FAIL("%s holds architecture %d, expected %d", path, d.arch, want_arch);
-    }
+    d.device = device;
+    if (want_arch && d.arch != want_arch) SRMI_FAIL("%s holds architecture %d, expected %d", path, d.arch, want_arch);
     srmi_model_t* m = nullptr;
-    if (srmi_model_create(&d, &m)) { fclose(f); return -1; }
+    if (srmi_model_create(&d, &m)) return -1;
+    // SRMI_GROWTH_ROUND8=0: plain f16 in RRDBNet's dense blocks (srmi_model_set_growth_round8)
+    const char* g = getenv("SRMI_GROWTH_ROUND8");
+    if (g && !strcmp(g, "0") && srmi_model_set_growth_round8(m, 0)) { srmi_model_destroy(m); return -1; }
     std::vector<float> data;
-    for (int i = 0; i < nt; ++i) {
-        int32_t nl, nd;
-        if (!read_exact(f, &nl, 4) || nl <= 0 || nl > 4096) goto bad;
-        {
-            std::string name(nl, '\0');
-            if (!read_exact(f, &name[0], nl) || !read_exact(f, &nd, 4) || nd < 0 || nd > 8) goto bad;
-            int64_t dims[8];
-            if (nd && !read_exact(f, dims, sizeof(int64_t) * nd)) goto bad;
-            int64_t n = 1;
-            for (int k = 0; k < nd; ++k) {
-                if (dims[k] < 0 || dims[k] > (1ll << 31)) goto bad;
-                n *= dims[k];
-                if (n > (1ll << 31)) goto bad;
-            }
-            data.resize((size_t)n);
-            if (!read_exact(f, data.data(), sizeof(float) * (size_t)n)) goto bad;
-            if (srmi_model_set_tensor(m, name.c_str(), data.data(), dims, nd)) { fclose(f); srmi_model_destroy(m); return -1; }
+    bool ok = nt >= 0;
+    for (int i = 0; i < nt && ok; ++i) {
+        int32_t nl = 0, nd = 0;
+        ok = read_exact(f, &nl, 4) && nl > 0 && nl <= 4096;
+        if (!ok) break;
+        std::string name(nl, '\0');
+        ok = read_exact(f, &name[0], nl) && read_exact(f, &nd, 4) && nd >= 0 && nd <= 8;
+        if (!ok) break;
+        int64_t dims[8];
+        ok = !nd || read_exact(f, dims, sizeof(int64_t) * nd);
+        if (!ok) break;
+        // a tensor cannot hold more floats than the file has bytes left for
+        const long left = file_size - ftell(f);
+        int64_t n = 1;
+        for (int k = 0; k < nd && ok; ++k) {
+            ok = dims[k] >= 0 && dims[k] <= (int64_t)left;
+            if (ok) { n *= dims[k]; ok = n <= (int64_t)left / 4; }
         }
+        if (!ok) break;
+        data.resize((size_t)n);
+        ok = read_exact(f, data.data(), sizeof(float) * (size_t)n);
+        if (!ok) break;
+        if (srmi_model_set_tensor(m, name.c_str(), data.data(), dims, nd)) { srmi_model_destroy(m); return -1; }
     }
-    fclose(f);
+    if (!ok) {
+        srmi_model_destroy(m);
+        SRMI_FAIL("%s is truncated or corrupt", path);
+    }
     if (srmi_model_finalize(m)) { srmi_model_destroy(m); return -1; }
     *out = m;
     *desc_out = d;
     return 0;
-bad:
+}
+
+}  // namespace srmi
+
+// Device a new runner context or executor binds to: $SRMI_DEVICE when set, else the calling thread's
+// current HIP device (so hipSetDevice(k) before <m>_init puts the context on GPU k).
+int srmi_pick_device(int* device) {
+    const char* e = getenv("SRMI_DEVICE");
+    if (e && *e) {
+        *device = atoi(e);
+        return 0;
+    }
+    SRMI_HIP(hipGetDevice(device));
+    return 0;
+}
+
+// Loads a weight file into a new model on `device`; `want_arch` (0 = any) guards against feeding e.g. an
+// EDSR file to rcan_init.  No exception leaves this function.
+int srmi_load_weight_file(const char* path, int want_arch, int device, srmi_model_t** out, srmi_model_desc_t* desc_out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) SRMI_FAIL("cannot open weight file %s", path);
+    long size = 0;
+    if (fseek(f, 0, SEEK_END) == 0) size = ftell(f);
+    rewind(f);
+    int rc = -1;
+    try {
+        rc = srmi::load_model_body(f, size, path, want_arch, device, out, desc_out);
+    } catch (const std::exception& e) {
+        srmi::set_error("%s: %s", path, e.what());
+    } catch (...) {
+        srmi::set_error("%s: unknown failure while loading", path);
+    }
     fclose(f);
-    srmi_model_destroy(m);
-    SRMI_FAIL("%s is truncated or corrupt", path);
+    return rc;
+}
+
+namespace srmi {
+
+static void runner_destroy(Runner* r) {
+    if (!r) return;
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->d_in) (void)hipFree(r->d_in);
+    if (r->d_resized) (void)hipFree(r->d_resized);
+    if (r->d_out) (void)hipFree(r->d_out);
+    if (r->model) srmi_model_destroy(r->model);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
 }
 
 static int runner_create(const char* path, int arch, int in_w, int in_h, Runner** out, int* scale) {
+    int device = 0;
+    if (srmi_pick_device(&device)) return -1;
     srmi_model_t* m = nullptr;
     srmi_model_desc_t d;
-    if (load_model(path, arch, &m, &d)) return -1;
+    if (srmi_load_weight_file(path, arch, device, &m, &d)) return -1;
     Runner* r = new Runner();
     r->model = m;
+    r->device = device;
     r->in_w = in_w; r->in_h = in_h; r->scale = d.scale;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
     const size_t in_bytes = (size_t)in_w * in_h * 3, out_bytes = in_bytes * d.scale * d.scale;
-    if (hipStreamCreate(&r->stream) != hipSuccess || hipMalloc((void**)&r->d_resized, in_bytes) != hipSuccess ||
-        hipMalloc((void**)&r->d_out, out_bytes) != hipSuccess) {
-        set_error("runner: device allocation failed");
-        srmi_model_destroy(m);
-        delete r;
+    // everything an inference needs is set up here, as the reference builds its executor and buffers in
+    // <m>_init (realesrgan.cpp:137-190): the first inference pays for no allocation
+    const bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&r->stream) == hipSuccess &&
+                    hipMalloc((void**)&r->d_resized, in_bytes) == hipSuccess &&
+                    hipMalloc((void**)&r->d_out, out_bytes) == hipSuccess;
+    if (!ok) set_error("runner: device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    const int rc = ok ? srmi_model_reserve_host(m, 1, in_h, in_w) : -1;
+    (void)hipSetDevice(prev);
+    if (rc) {
+        runner_destroy(r);
         return -1;
     }
     *out = r;
@@ -118,43 +201,21 @@ static int runner_create(const char* path, int arch, int in_w, int in_h, Runner*
     return 0;
 }
 
-static void runner_destroy(Runner* r) {
-    if (!r) return;
-    (void)hipStreamSynchronize(r->stream);
-    if (r->d_in) (void)hipFree(r->d_in);
-    (void)hipFree(r->d_resized);
-    (void)hipFree(r->d_out);
-    srmi_model_destroy(r->model);
-    (void)hipStreamDestroy(r->stream);
-    delete r;
-}
-
 // u8 HWC host image (w x h) -> malloc()ed u8 HWC host image of the model's output size.
 static int runner_run(Runner* r, const unsigned char* rgb, int w, int h, unsigned char** out) {
-    const size_t in_bytes = (size_t)w * h * 3;
-    const uint8_t* d_src;
-    if (w == r->in_w && h == r->in_h) {
-        SRMI_HIP(hipMemcpyAsync(r->d_resized, rgb, in_bytes, hipMemcpyHostToDevice, r->stream));
-        d_src = r->d_resized;
-    } else {
-        if (in_bytes > r->in_cap) {
-            if (r->d_in) SRMI_HIP(hipFree(r->d_in));
-            r->d_in = nullptr; r->in_cap = 0;
-            SRMI_HIP(hipMalloc((void**)&r->d_in, in_bytes));
-            r->in_cap = in_bytes;
-        }
-        SRMI_HIP(hipMemcpyAsync(r->d_in, rgb, in_bytes, hipMemcpyHostToDevice, r->stream));
-        if (srmi_resize_bilinear_u8(r->d_in, w, h, r->d_resized, r->in_w, r->in_h, r->stream)) return -1;
-        d_src = r->d_resized;
-    }
-    if (srmi_model_forward_u8(r->model, d_src, r->d_out, 1, r->in_h, r->in_w, SRMI_ROUND_HALF_UP, r->stream)) return -1;
     const size_t out_bytes = (size_t)r->in_w * r->in_h * 3 * r->scale * r->scale;
     unsigned char* host = (unsigned char*)malloc(out_bytes);
     if (!host) SRMI_FAIL("runner: cannot allocate %zu bytes for the output image", out_bytes);
-    if (hipMemcpyAsync(host, r->d_out, out_bytes, hipMemcpyDeviceToHost, r->stream) != hipSuccess ||
-        hipStreamSynchronize(r->stream) != hipSuccess) {
+    int rc;
+    if (w == r->in_w && h == r->in_h) {
+        // pinned staging, copies on the lane's stream (srmi_model_forward_u8_host)
+        rc = srmi_model_forward_u8_host(r->model, rgb, host, 1, h, w, SRMI_ROUND_HALF_UP);
+    } else {
+        rc = runner_run_resized(r, rgb, w, h, host, out_bytes);
+    }
+    if (rc) {
         free(host);
-        SRMI_FAIL("runner: device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return -1;
     }
     *out = host;
     return 0;

@@ -93,14 +93,46 @@ class Engine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _check_out(self, out, shape, dtype):
+        """A caller-supplied result tensor is handed to the kernels as a raw pointer: it must be exactly the
+        dense tensor they write."""
+        if (out.dtype != dtype or out.device != self.device or tuple(out.shape) != tuple(shape)
+                or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}, got "
+                             f"{out.dtype} {tuple(out.shape)} on {out.device}"
+                             f"{'' if out.is_contiguous() else ' (not contiguous)'}")
+        return out
+
+    def reserve(self, n, h, w, host=False):
+        """Allocate everything a later forward of up to n frames of h x w needs (workspace, lanes; with
+        host=True also the pinned staging of forward_u8_host)."""
+        fn = lib().srmi_model_reserve_host if host else lib().srmi_model_reserve
+        check(fn(self._h, int(n), int(h), int(w)), "srmi_model_reserve")
+
+    def forward_u8_host(self, imgs: np.ndarray, round_mode=_lib.ROUND_HALF_UP, out: np.ndarray = None) -> np.ndarray:
+        """uint8 NHWC frames in host memory -> uint8 NHWC frames in host memory; transfers overlap compute."""
+        a = np.ascontiguousarray(imgs)
+        if a.ndim != 4 or a.shape[3] != 3 or a.dtype != np.uint8:
+            raise ValueError(f"expected uint8 [N,H,W,3], got {a.dtype} {a.shape}")
+        n, h, w, _ = a.shape
+        shape = (n, h * self.scale, w * self.scale, 3)
+        if out is None:
+            out = np.empty(shape, dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.shape != shape or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous uint8 array of shape {shape}")
+        check(lib().srmi_model_forward_u8_host(self._h, a.ctypes.data, out.ctypes.data, n, h, w, round_mode),
+              "srmi_model_forward_u8_host")
+        return out
+
     def forward_f32(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """x: float32 NCHW on this engine's GPU -> float32 NCHW [n,3,h*scale,w*scale]."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected [N,3,H,W], got {tuple(x.shape)}")
         x = x.to(self.device, torch.float32).contiguous()
         n, _, h, w = x.shape
-        if out is None:
-            out = torch.empty((n, 3, h * self.scale, w * self.scale), dtype=torch.float32, device=self.device)
+        shape = (n, 3, h * self.scale, w * self.scale)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device) if out is None else \
+            self._check_out(out, shape, torch.float32)
         check(lib().srmi_model_forward_f32(self._h, x.data_ptr(), out.data_ptr(), n, h, w, self._stream()),
               "srmi_model_forward_f32")
         return out
@@ -114,8 +146,9 @@ class Engine:
             raise ValueError(f"expected uint8 [N,H,W,3], got {img.dtype} {tuple(img.shape)}")
         img = img.to(self.device).contiguous()
         n, h, w, _ = img.shape
-        if out is None:
-            out = torch.empty((n, h * self.scale, w * self.scale, 3), dtype=torch.uint8, device=self.device)
+        shape = (n, h * self.scale, w * self.scale, 3)
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device) if out is None else \
+            self._check_out(out, shape, torch.uint8)
         check(lib().srmi_model_forward_u8(self._h, img.data_ptr(), out.data_ptr(), n, h, w, round_mode,
                                           self._stream()), "srmi_model_forward_u8")
         return out[0] if squeeze else out
