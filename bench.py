@@ -105,6 +105,60 @@ def pmc_traffic(arch, dtype):
         return None
 
 
+def side_config(arch, dtype, h, w, batch, steps, device, lanes=3):
+    """A BASELINE configuration other than the headline one, measured in the same process (u8 in HBM -> u8 in
+    HBM, HIP-event time on the launch stream): output Mpix/s, ms per frame and the conv kernel's MFMA fraction."""
+    from superresolution_amd import _lib, synth
+    model, _ = build_model(arch, dtype, False, device)
+    eng = model.engine()
+    eng.set_lanes(lanes)
+    scale = eng.scale
+    imgs = torch.from_numpy(synth.random_image(h, w, 300, n=batch)).cuda()
+    out = torch.empty((batch, h * scale, w * scale, 3), dtype=torch.uint8, device="cuda")
+    eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
+    ev1.record()
+    torch.cuda.synchronize()
+    sec = ev0.elapsed_time(ev1) / 1e3
+    frames = batch * steps
+    tflops = eng.flops(h, w) * frames / sec / 1e12
+    rec = {"workload": f"{arch} x{scale} {w}x{h}->{w * scale}x{h * scale}, batch {batch}, u8 in HBM -> u8 in HBM",
+           "dtype": dtype, "value": round(frames * h * scale * w * scale / 1e6 / sec, 2), "unit": "Mpix/s",
+           "ms_per_frame": round(sec / frames * 1e3, 4),
+           "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                        "frac": round(tflops / MFMA_PEAK_TFLOPS[dtype], 4)}}
+    del eng, model
+    torch.cuda.empty_cache()
+    return rec
+
+
+def host_path(eng, h, w, batch, steps, rank):
+    """The reference API's shape (host u8 image in, host u8 image out; realesrgan.cpp:217-257), PCIe transfers and
+    host copies included: srmi_model_forward_u8_host on pageable numpy frames, wall clock."""
+    from superresolution_amd import _lib, synth
+    imgs = synth.random_image(h, w, 200 + rank, n=batch)
+    out = np.empty((batch, h * eng.scale, w * eng.scale, 3), dtype=np.uint8)
+    eng.forward_u8_host(imgs, _lib.ROUND_HALF_UP, out=out)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward_u8_host(imgs, _lib.ROUND_HALF_UP, out=out)
+    sec = time.perf_counter() - t0
+    one = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        eng.forward_u8_host(imgs[:1], _lib.ROUND_HALF_UP, out=out[:1])
+        one.append(time.perf_counter() - t1)
+    return {"value": round(batch * steps * h * eng.scale * w * eng.scale / 1e6 / sec, 2), "unit": "Mpix/s",
+            "ms_per_frame": round(sec / (batch * steps) * 1e3, 4),
+            "single_frame_latency_ms": round(sorted(one)[2] * 1e3, 3),
+            "note": f"{batch} pageable host frames in -> host frames out per call, H2D/D2H and host copies inside the "
+                    "timed region, wall clock"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +177,8 @@ def main():
                     help="keep an extra f32 copy of the residual trunk (default: f16 trunk, which meets the same "
                          "1-LSB / 50 dB parity bound at this workload, tests/test_models_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the EDSR / RCAN configurations and the host-buffer rate that a default 1-GPU run adds")
     ap.add_argument("--plain-f16", action="store_true",
                     help="RRDBNet f16: keep 11 significant bits in the dense blocks' grown channels too "
                          "(default: 8 there, srmi_model_set_growth_round8)")
@@ -271,10 +327,24 @@ def main():
                                          "frac": round(flops_frame / serial / 1e12 / peak, 4),
                                          "avg_launch_us": round(serial / launches * 1e6, 3),
                                          "note": "one lane: launches run back to back, as under rocprofv3 --kernel-trace"}
+        if not args.no_side_configs and world == 1 and args.model == "rrdbnet" and args.streams == 1:
+            hp = host_path(eng, h, w, batch, max(2, args.steps // 4), rank)
+            hp["frac_of_hbm_resident_rate"] = round(hp["value"] / rec["value"], 3)
+            rec["e2e_host"] = hp
+            # free the headline model's workspace before the other networks take theirs
+            side_steps = max(2, args.steps // 5)
+            rec["other_configs"] = {
+                "edsr_x4_256x256_batch32_bf16": side_config("edsr", "bf16", 256, 256, 32, side_steps, local_rank),
+                "edsr_x4_256x256_batch32_f16": side_config("edsr", "f16", 256, 256, 32, side_steps, local_rank),
+                "rcan_x4_510x339_f16": side_config("rcan", "f16", 339, 510, 12, side_steps, local_rank),
+            }
         if not args.no_cpu_baseline and world == 1:
+            # 16 = the CPU share of a one-GPU box of this pool (its OMP_NUM_THREADS); os.cpu_count() there reports
+            # the whole machine.  On a smaller host all cores are used.
             threads = min(16, os.cpu_count() or 1)
             v, sample = cpu_baseline(args.model, sd, h, w, threads)
             rec["cpu_baseline"] = {"value": round(v, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
+                                   "cores_note": "the box's per-GPU CPU share (16) or the host's core count if smaller",
                                    "sample": sample}
         print(json.dumps(rec))
     if dist is not None:
