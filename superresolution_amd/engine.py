@@ -84,6 +84,12 @@ class Engine:
         """Internal HIP streams (1..4) the sweeps of one call are spread over; results do not depend on it."""
         check(lib().srmi_model_set_lanes(self._h, int(lanes)), "srmi_model_set_lanes")
 
+    def set_rgb_shift(self, shift):
+        """Core (no-MeanShift) EDSR / RCAN on the u8 path: subtract shift[c] before the first conv and add it back
+        after the last (the runners' rgb_mean * rgb_range, edsr.cpp:36-37,116)."""
+        v = (C.c_float * 3)(*[float(x) for x in shift])
+        check(lib().srmi_model_set_rgb_shift(self._h, v), "srmi_model_set_rgb_shift")
+
     def workspace_bytes(self):
         return int(lib().srmi_model_workspace_bytes(self._h))
 

@@ -56,3 +56,37 @@ def convert_checkpoint(checkpoint_path, out_path, arch=None, scale=None):
     else:
         model, _ = load_realesrgan_from_checkpoint(checkpoint_path)
     return save_weights(model, out_path)
+
+
+def load_weights(path, **engine_kwargs):
+    """Read a runner weight file back into the matching module of this package (EDSR / EDSRCore / RCAN /
+    RCANCore / RRDBNet), weights loaded.  engine_kwargs: compute_dtype, trunk_f32, device, ..."""
+    from .edsr_model import EDSR, EDSRCore
+    from .rcan_model import RCAN, RCANCore
+    from .realesrgan_model import RRDBNet
+    with open(path, "rb") as f:
+        if f.read(8) != b"SRMIW001":
+            raise ValueError(f"{path} is not an SRMIW001 weight file")
+        arch, scale, nf, nb, ng, gc, red, ms = struct.unpack("<8i", f.read(32))
+        (rs,) = struct.unpack("<f", f.read(4))
+        (nt,) = struct.unpack("<i", f.read(4))
+        sd = {}
+        for _ in range(nt):
+            (nl,) = struct.unpack("<i", f.read(4))
+            name = f.read(nl).decode()
+            (nd,) = struct.unpack("<i", f.read(4))
+            dims = struct.unpack(f"<{nd}q", f.read(8 * nd))
+            n = int(np.prod(dims)) if nd else 1
+            sd[name] = torch.from_numpy(np.frombuffer(f.read(4 * n), dtype="<f4").reshape(dims).copy())
+    if arch == _lib.ARCH_RRDBNET:
+        model = RRDBNet(num_feat=nf, num_block=nb, num_grow_ch=gc, scale=scale, **engine_kwargs)
+    elif arch == _lib.ARCH_EDSR:
+        cls = EDSR if ms else EDSRCore
+        model = cls(n_resblocks=nb, n_feats=nf, scale=scale, res_scale=rs, **engine_kwargs)
+    elif arch == _lib.ARCH_RCAN:
+        cls = RCAN if ms else RCANCore
+        model = cls(scale=scale, n_resgroups=ng, n_resblocks=nb, n_feats=nf, reduction=red, res_scale=rs, **engine_kwargs)
+    else:
+        raise ValueError(f"{path}: unknown architecture {arch}")
+    model.load_state_dict(sd, strict=True)
+    return model

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "ops.npz")
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("ops.npz", "prepost_ref.npz"))
 
 
 def load_case(tag):
@@ -66,7 +66,13 @@ def build_model(meta, compute_dtype, trunk_f32=True):
     return m, sd
 
 
-# fp32 parity bound of the task statement: max-abs <= 1e-4 on the [0,1] image scale; EDSR / RCAN
-# work in the 0..255 domain (rgb_range = 255), so the same bound reads 1e-4 * 255 there.
+# fp32 parity bound: max-abs <= 1e-4 on RRDBNet's [0,1] image scale (the task statement's figure).  EDSR / RCAN
+# work in the 0..255 domain (rgb_range = 255); there the bound is the reference's own for that domain, 1e-3
+# absolute (edsr/mtk/python/test/test_pytorch.py:187) = 3.9e-6 of the image scale.
 def f32_tol(meta):
-    return 1e-4 if meta["input"] == "unit" else 1e-4 * 255.0
+    return 1e-4 if meta["input"] == "unit" else 1e-3
+
+
+def prepost_ref():
+    """Outputs of the reference's own Python pre/post-processing functions (tools/make_golden_prepost.py)."""
+    return np.load(os.path.join(GOLDEN, "prepost_ref.npz"))

@@ -116,6 +116,30 @@ def test_edsr_batch_configuration_full_size():
         assert np.array_equal(out[i], got[i % 4]), i
 
 
+def test_edsr_batch_configuration_full_size_bf16():
+    """The configuration the baseline names in bf16 (EDSR x4, 256x256, batch 32), run in bf16 at full size and
+    depth: its error against the oracle is RECORDED and bounded by what bf16 operands deliver, which is not the
+    1-LSB bound: with 8 significant bits per conv operand in the 0..255 domain a few pixels move by 2-3 LSB while
+    the PSNR stays above 50 dB.  The 1-LSB / 50 dB half-precision bound is met by the f16 engine (test above)."""
+    meta = _u8_case("edsr")
+    model, sd = H.build_model(meta, "bf16")
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    imgs = np.stack([synth.smooth_image(256, 256, 40), synth.random_image(256, 256, 41)])
+    batch = torch.from_numpy(np.concatenate([imgs] * 16)).cuda()          # 32 frames
+    out = model.engine().forward_u8(batch).cpu().numpy()
+    assert out.shape == (32, 1024, 1024, 3)
+    for i, kind in enumerate(("smooth", "noise")):
+        with torch.no_grad():
+            ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(imgs[i])), O.ROUND_HALF_UP)[0]
+        diff = np.abs(out[i].astype(np.int32) - ref.astype(np.int32))
+        psnr = O.psnr_u8(out[i], ref)
+        print(f"edsr 256x256 batch 32 bf16 ({kind}): max u8 diff {diff.max()}, > 1 LSB on {100 * (diff > 1).mean():.4f} % of "
+              f"the samples, differing {100 * (diff != 0).mean():.2f} %, PSNR {psnr:.2f} dB")
+        assert diff.max() <= 3 and (diff > 1).mean() < 0.01 and psnr >= 50.0
+    for i in range(32):
+        assert np.array_equal(out[i], out[i % 2]), i
+
+
 def test_rcan_configuration_full_size_frame():
     """RCAN x4 (10 groups x 20 blocks) on a 510x339 frame against the oracle: the channel-attention means run
     over 172 890 pixels in 464 tile partial sums."""

@@ -147,6 +147,28 @@ def test_rgb_tail(dt, name, tol):
         assert 0.02 < (ref8 == 0).mean() < 0.9  # clamping is exercised
 
 
+def test_u8_tail_matches_the_reference_python_postprocess():
+    """The HIP u8 tail on exact .5 ties, near-ties and out-of-range values against the outputs of the reference's
+    own postprocess / save_image functions (tests/golden/prepost_ref.npz).  An f32 convolution whose only non-zero
+    weights are 1.0 on the centre tap of channels 0..2 hands the tensor to the tail unchanged."""
+    from tests import helpers as H
+    z = H.prepost_ref()
+    t = torch.from_numpy(z["t"])
+    x = torch.zeros((1, 8, t.shape[2], t.shape[3]))
+    x[:, :3] = t
+    wt = np.zeros((3, 8, 3, 3), np.float32)
+    for c in range(3):
+        wt[c, c, 1, 1] = 1.0
+    pc = ops.PackedConv(wt, np.zeros(3, np.float32), _lib.F32, cout_tile=32)
+    xp = ops.Planes.from_nchw(x, _lib.F32)
+    for mode, key in [(_lib.ROUND_HALF_EVEN, "post_half_even_edsr_rknn"), (_lib.ROUND_HALF_EVEN, "post_half_even_rcan_rknn"),
+                      (_lib.ROUND_TRUNC, "post_trunc_edsr_mtk")]:
+        got = ops.conv3x3(xp, pc, tail=dict(mode=_lib.TAIL_U8_NHWC, lo=0.0, hi=255.0, scale=1.0, round=mode))
+        assert np.array_equal(got.cpu().numpy()[0], z[key]), key
+    got = ops.conv3x3(xp, pc, tail=dict(mode=_lib.TAIL_U8_NHWC, lo=0.0, hi=255.0, scale=1.0, round=_lib.ROUND_HALF_UP))
+    assert np.array_equal(got.cpu().numpy(), O.post_range(t, O.ROUND_HALF_UP))
+
+
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
 @pytest.mark.parametrize("mb", [2, 3])
 def test_chansum(dt, name, tol, mb):

@@ -153,3 +153,31 @@ def test_demo_cli_png_in_png_out(tmp_path, capsys):
     assert demo.main(["demo", wpath, ipath]) == -1
     assert demo.main(["demo", wpath, str(tmp_path / "missing.png"), opath]) == -1
     assert demo.main(["demo", str(tmp_path / "missing.srmi"), ipath, opath]) == -1
+
+
+def test_batch_driver_directory_and_stream(tmp_path):
+    """Directory driver: mixed sizes, a frame larger than the tile size, weight file read back from disk; every
+    output file equals the single-frame runner result (whole frames) or the tiled upscale (large frame)."""
+    from PIL import Image
+    from superresolution_amd import batch, sharding
+    meta = dict(arch="rrdbnet", num_block=1, scale=4, seed=44, input="unit")
+    model, _ = H.build_model(meta, "f16")
+    wpath = str(tmp_path / "RealESRGAN_x4plus_batch.srmi")
+    export.save_weights(model, wpath)
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    frames = {}
+    for i, (h, w) in enumerate([(40, 56)] * 5 + [(33, 47)] * 2 + [(96, 120)]):
+        frames[f"f{i:02d}.png"] = synth.random_image(h, w, 60 + i)
+        Image.fromarray(frames[f"f{i:02d}.png"], "RGB").save(src / f"f{i:02d}.png")
+    assert batch.main([wpath, str(src), str(dst), "--batch", "3", "--tile", "64", "64", "--halo", "8", "--suffix", "_x4"]) == 0
+    loaded = batch.load_model(wpath, compute_dtype="f16")
+    fwd = lambda t: loaded.engine().forward_u8(t.cuda(), _lib.ROUND_HALF_UP)  # noqa: E731
+    for name, img in frames.items():
+        got = np.asarray(Image.open(dst / name.replace(".png", "_x4.png")))
+        if img.shape[0] > 64:
+            want = sharding.upscale_tiled(fwd, torch.from_numpy(img), 4, 64, 64, 8).cpu().numpy()
+        else:
+            want = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+        assert np.array_equal(got, want), name
+    assert batch.main([str(tmp_path / "missing.srmi"), str(src), str(dst)]) == -1
