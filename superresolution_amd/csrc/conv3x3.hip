@@ -42,7 +42,7 @@
 // passes -DSRMI_DIAG with them); the shipped library is built without any of them.
 #if !defined(SRMI_DIAG) && (defined(SRMI_ABL_NO_DMA) || defined(SRMI_ABL_NO_DMA_A) || defined(SRMI_ABL_NO_DMA_B) || \
                             defined(SRMI_ABL_NO_LDS) || defined(SRMI_STAMPS) || defined(SRMI_BULK_ISSUE) ||          \
-                            defined(SRMI_SINGLE_FRAG) || defined(SRMI_NO_XCD_MAP) || defined(SRMI_CLOCK) || defined(SRMI_NW) || defined(SRMI_RING))
+                            defined(SRMI_SINGLE_FRAG) || defined(SRMI_NO_XCD_MAP) || defined(SRMI_CLOCK) || defined(SRMI_STAMPS_EPI) || defined(SRMI_GAP_OVERRIDE) || defined(SRMI_NW) || defined(SRMI_RING))
 #error "diagnostic kernel variants need -DSRMI_DIAG"
 #endif
 
@@ -86,9 +86,14 @@ struct ConvGeom {
 #ifndef SRMI_RING
 #define SRMI_RING 2
 #endif
-    static constexpr int NS = (SRMI_RING == 3 && 3 * STAGE_BYTES + 32 * NB * 4 <= 80 * 1024) ? 3 : 2;
-    static constexpr int LDS_BYTES = NS * STAGE_BYTES;     // + 32*NB floats of bias behind it
-    static constexpr int LDS_TOTAL = LDS_BYTES + 32 * NB * 4;
+    static constexpr int NS = (SRMI_RING == 3 && 3 * STAGE_BYTES <= 80 * 1024) ? 3 : 2;
+    static constexpr int LDS_BYTES = NS * STAGE_BYTES;
+    // the epilogue's bias and tile-sum scratch alias the stage buffers (written after the last stage), so
+    // an 8-row tile needs exactly 40 KiB and four workgroups share a CU's 160 KiB, a 12-row tile 48 KiB (three)
+    static constexpr int LDS_TOTAL = LDS_BYTES;
+    static constexpr int BIAS_OFFSET = 8192;               // behind the tile sums (kNW * 32 * NB floats <= 8 KiB)
+    // waves per SIMD the register budget is held to: 4 for the 8-row tile (<= 128 registers), else 2
+    static constexpr int MIN_WAVES = (MB == 2 && NB == 1 && kNW == 4) ? 4 : (kNW == 4 ? 2 : 4);
 };
 
 #define SRMI_OOB_OFFSET 0xFFFFFFF0u  // beyond every descriptor's num_records -> reads 0
@@ -273,7 +278,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[b][q][j] = v[b][q][j] >= 0.f ? v[b][q][j] : v[b][q][j] * 0.2f;
+                    for (int j = 0; j < 8; ++j) v[b][q][j] = fmaxf(v[b][q][j], v[b][q][j] * 0.2f);  // slope < 1
         }
         if (has_res1) {
             float rr[NB][2][8];
@@ -316,7 +321,8 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                         st8<OUT2>(p.out2, k.n, pix, (k.ct * NB + b) * 32 + 16 * q + 8 * k.lh, v[b][q]);
             }
             if (has_out) {
-                if (p.out.flags & SRMI_TENSOR_ROUND8) {
+                const bool round8 = (p.out.flags & SRMI_TENSOR_ROUND8) != 0;
+                if (round8) {
                     // 8 significant bits (round to nearest even), then the cast of the store below
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
@@ -417,7 +423,7 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 }
 
 template <int DT, int MB, int NB>
-__global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     using G = ConvGeom<MB, NB>;
     constexpr int TH = G::TH, PW = G::PW;
@@ -563,7 +569,8 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
 #endif
     STAMP();
     issue(0, 0);
-    if (tid < 32 * NB) ((float*)(smem + G::LDS_BYTES))[tid] = p.bias[ct * 32 * NB + tid];
+    // this thread's bias value waits in a register until the stage buffers are free
+    const float bias_v = tid < 32 * NB ? p.bias[ct * 32 * NB + tid] : 0.f;
     if (G::NS == 3 && nstage > 1) issue(1, 1);
     STAMP();
 
@@ -609,7 +616,11 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
             }
         }
     };
+#ifdef SRMI_GAP_OVERRIDE  // diagnostic build: issue the next stage's pieces closer together, earlier in the stage
+    constexpr int GAP = SRMI_GAP_OVERRIDE;
+#else
     constexpr int GAP = (9 * MB * NB) / PPW;  // multiply steps between two DMA pieces
+#endif
     static_assert(GAP >= 1, "a stage needs at least as many multiply steps as DMA pieces per wave");
 
     // Two main loops; long reductions take the first (measured: +3 % on EDSR's 16-stage layers, +1 % on
@@ -756,15 +767,23 @@ __global__ __launch_bounds__(64 * kNW, kNW == 4 ? 2 : 4) void conv3x3_kernel(con
         cur = cur + 1 == G::NS ? 0 : cur + 1;
     }
     }  // classic loop
-    // the epilogue reuses the stage buffers (channel sums) and reads the bias: all waves must be
-    // out of the main loop first
+    // the epilogue reuses the stage buffers (bias, channel sums): all waves must be out of the main loop
+    // first
     __syncthreads();
+#ifdef SRMI_STAMPS_EPI
+    STAMP();
+#endif
+    if (tid < 32 * NB) ((float*)(smem + G::BIAS_OFFSET))[tid] = bias_v;
+    __syncthreads();
+#ifdef SRMI_STAMPS_EPI
+    STAMP();
+#endif
 
     // ---- epilogue --------------------------------------------------------------------------------
     // One uniform switch selects straight-line code specialised for the tensor types in use; the
     // combinations the networks need are compiled, anything else takes the generic path.
     const EpiCtx ctx{n, ct, tile, x0, y0, wave, lx, lh, tid};
-    const float* lds_bias = (const float*)(smem + G::LDS_BYTES);
+    const float* lds_bias = (const float*)(smem + G::BIAS_OFFSET);
     float* lds_red = (float*)smem;
     const int od = p.out.ptr ? p.out.dtype : -1, rd = p.res1.ptr ? p.res1.dtype : -1;
     const int r2 = p.res2.ptr ? p.res2.dtype : -1, o2 = p.out2.ptr ? p.out2.dtype : -1;
