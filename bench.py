@@ -105,6 +105,53 @@ def pmc_traffic(arch, dtype):
         return None
 
 
+def w8a8_peak(model, flops_frame, h, w):
+    """Effective dense peak of the mixed network: the dense blocks' FLOPs are priced at the int8 rate (2 x the f16
+    rate: 5000 TOP/s), everything else at 2500 TFLOP/s; peak = total FLOPs / roofline time."""
+    nf, gc = model.num_feat, model.num_grow_ch
+    rdb = sum(2.0 * (nf + j * gc) * gc * 9 for j in range(4)) + 2.0 * (nf + 4 * gc) * nf * 9
+    f_i8 = 3 * model.num_block * rdb * h * w
+    t = f_i8 / 5000.0 + (flops_frame - f_i8) / 2500.0
+    return round(flops_frame / t, 1)
+
+
+def w8a8_config(h, w, batch, steps, device, lanes=3):
+    """RealESRGAN_x4plus with int8 dense blocks (the reference's w8a8 deployment): throughput, and accuracy against the
+    f16 engine on the same frames (the reference quotes its INT8 model against its FP16 one: 33.34 dB)."""
+    from superresolution_amd import _lib, synth
+    model, _ = build_model("rrdbnet", "f16", False, device)
+    eng = model.engine()
+    eng.set_lanes(lanes)
+    imgs = torch.from_numpy(synth.random_image(h, w, 400, n=batch)).cuda()
+    imgs[0] = torch.from_numpy(synth.smooth_image(h, w, 7)).cuda()
+    ref = eng.forward_u8(imgs[:2], _lib.ROUND_HALF_UP).cpu().numpy().astype(np.float64)
+    eng.calibrate(np.stack([synth.smooth_image(h, w, 900 + i) for i in range(4)] +
+                           [synth.random_image(h, w, 950 + i) for i in range(2)]), batch=3)
+    out = torch.empty((batch, h * 4, w * 4, 3), dtype=torch.uint8, device="cuda")
+    eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
+    torch.cuda.synchronize()
+    got = out[:2].cpu().numpy().astype(np.float64)
+    psnr = [float(10 * np.log10(255.0 ** 2 / max(np.mean((got[i] - ref[i]) ** 2), 1e-12))) for i in range(2)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
+    ev1.record()
+    torch.cuda.synchronize()
+    sec = ev0.elapsed_time(ev1) / 1e3
+    frames = batch * steps
+    flops_frame = eng.flops(h, w)
+    tflops = flops_frame * frames / sec / 1e12
+    peak = w8a8_peak(model, flops_frame, h, w)
+    return {"workload": f"rrdbnet x4 {w}x{h}->{w * 4}x{h * 4}, batch {batch}, int8 dense blocks (w8a8), f16 elsewhere",
+            "dtype": "i8/f16", "value": round(frames * h * 4 * w * 4 / 1e6 / sec, 2), "unit": "Mpix/s",
+            "ms_per_frame": round(sec / frames * 1e3, 4),
+            "psnr_vs_f16_engine_db": {"smooth": round(psnr[0], 2), "noise": round(psnr[1], 2)},
+            "max_u8_diff_vs_f16_engine": int(np.abs(got - ref).max()),
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": peak, "unit": "TOP/s (int8 + f16 mix)",
+                         "frac": round(tflops / peak, 4)}}
+
+
 def side_config(arch, dtype, h, w, batch, steps, device, lanes=3):
     """A BASELINE configuration other than the headline one, measured in the same process (u8 in HBM -> u8 in
     HBM, HIP-event time on the launch stream): output Mpix/s, ms per frame and the conv kernel's MFMA fraction."""
@@ -182,6 +229,9 @@ def main():
     ap.add_argument("--plain-f16", action="store_true",
                     help="RRDBNet f16: keep 11 significant bits in the dense blocks' grown channels too "
                          "(default: 8 there, srmi_model_set_growth_round8)")
+    ap.add_argument("--w8a8", action="store_true",
+                    help="RRDBNet: calibrate on synthetic frames and run the dense blocks in int8 (a lower-precision "
+                         "configuration of its own; never the headline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier and the max-over-ranks reduce (gloo: rehearsal of the "
                          "multi-rank path on a box with fewer GPUs than ranks; ranks then share devices)")
@@ -221,6 +271,9 @@ def main():
         engs.append(model.engine())
         engs[-1].set_sweep(args.sweep)
         engs[-1].set_lanes(args.lanes)
+        if args.w8a8:
+            engs[-1].calibrate(np.stack([synth.smooth_image(h, w, 900 + i) for i in range(4)] +
+                                        [synth.random_image(h, w, 950 + i) for i in range(2)]), batch=3)
     eng = engs[0]
     scale = eng.scale
     imgs = torch.from_numpy(synth.random_image(h, w, 100 + rank, n=batch)).cuda()
@@ -288,6 +341,8 @@ def main():
         launches = conv_launches_per_frame(models[0])
         achieved = flops_frame * batch * args.steps / dev_s / 1e12  # per GPU
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        if args.w8a8:
+            peak = w8a8_peak(models[0], flops_frame, h, w)
         rec = {
             "metric": "output Mpix/sec, RealESRGAN_x4plus 510x339->x4" if args.model == "rrdbnet"
                       else f"output Mpix/sec, {args.model} x4",
@@ -308,8 +363,11 @@ def main():
                        "frames_per_gpu_per_step": batch, "sweep": args.sweep, "lanes": args.lanes,
                        "streams": args.streams,
                        "trunk_f32": args.trunk_f32,
-                       "precision": ("f16 operands, f32 accumulation; dense-block grown channels x1..x4 and the weights of "
-                                     "conv1-4 / grown columns of conv5 carry 8 significant bits")
+                       "precision": "w8a8: int8 operands / int32 accumulation in the dense blocks (calibrated per-tensor "
+                                    "activation scales, per-channel weight scales), f16 trunk and outer layers"
+                       if args.w8a8 else
+                       ("f16 operands, f32 accumulation; dense-block grown channels x1..x4 and the weights of "
+                        "conv1-4 / grown columns of conv5 carry 8 significant bits")
                        if (args.model == "rrdbnet" and args.dtype == "f16" and not args.plain_f16)
                        else f"{args.dtype} operands, f32 accumulation",
                        "parallelism": f"frame-sharded x{world}, no collective"},
@@ -337,6 +395,7 @@ def main():
                 "edsr_x4_256x256_batch32_bf16": side_config("edsr", "bf16", 256, 256, 32, side_steps, local_rank),
                 "edsr_x4_256x256_batch32_f16": side_config("edsr", "f16", 256, 256, 32, side_steps, local_rank),
                 "rcan_x4_510x339_f16": side_config("rcan", "f16", 339, 510, 12, side_steps, local_rank),
+                "rrdbnet_x4_510x339_w8a8": w8a8_config(339, 510, 12, side_steps, local_rank),
             }
         if not args.no_cpu_baseline and world == 1:
             # 16 = the CPU share of a one-GPU box of this pool (its OMP_NUM_THREADS); os.cpu_count() there reports

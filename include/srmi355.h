@@ -34,6 +34,7 @@ extern "C" {
 #define SRMI_F32 0
 #define SRMI_F16 1
 #define SRMI_BF16 2
+#define SRMI_I8 3  /* signed 8-bit, symmetric, value = q / qscale; 32 channels per plane (w8a8 path) */
 
 /* activations fused into the conv epilogue */
 #define SRMI_ACT_NONE 0
@@ -69,8 +70,10 @@ typedef struct {
     void* ptr;            /* device pointer to plane 0 of image 0 (NULL = absent) */
     int64_t img_stride;   /* elements between images */
     int64_t plane_stride; /* elements between planes */
-    int32_t dtype;        /* SRMI_F32 / SRMI_F16 / SRMI_BF16 */
+    int32_t dtype;        /* SRMI_F32 / SRMI_F16 / SRMI_BF16 / SRMI_I8 */
     int32_t flags;        /* SRMI_TENSOR_* bits, 0 = none */
+    float qscale;         /* SRMI_I8 tensors: stored q = clamp(rint(value * qscale), -127, 127) */
+    int32_t reserved;
 } srmi_tensor_t;
 
 /* Honoured on `out` of srmi_conv3x3: values are rounded to 8 significant bits (bfloat16's precision,
@@ -98,6 +101,9 @@ typedef struct {
  * through F.interpolate(scale_factor=2, mode='nearest') (realesrgan_model.py:110,113).
  * With ps_r > 1 the `cout` output channels are stored as nn.PixelShuffle(ps_r) would
  * (edsr_model.py:57,67): out is (h*ps_r, w*ps_r) with cout/ps_r^2 channels.
+ * With dtype SRMI_I8 (the reference's w8a8 deployment, realesrgan/rknn/python/convert.py:198-278) the input tensor
+ * and the packed weights are int8 (weights: integer-valued floats handed to srmi_pack_conv3x3), accumulation is
+ * exact in int32, and v = acc * wscale[o] + bias[o]; outputs and residuals may be of any element type.
  * cin must be a multiple of the plane width; cout a multiple of 32, or 3 with a tail.
  * Weights come from srmi_pack_conv3x3 for the same (dtype, cout_tile, ps_r).
  */
@@ -123,6 +129,10 @@ typedef struct {
     float tail_bias[3];
     float tail_lo, tail_hi, tail_scale;
     int32_t tail_round;
+    /* dtype SRMI_I8 (int8 operands, int32 accumulation on the matrix cores): the accumulator of output channel o
+     * is multiplied by wscale[o] (= weight scale * input activation scale, packed order like `bias`) before the
+     * bias is added; NULL for the float types. */
+    const float* wscale;
 } srmi_conv_desc_t;
 
 int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream);
@@ -178,6 +188,11 @@ int srmi_ca_apply(const srmi_tensor_t* y, const srmi_tensor_t* x, const float* s
  * (rcan_model.py:65,74) as a standalone wavefront reduction.  sums: float[n][c]. */
 int srmi_channel_sums(const srmi_tensor_t* x, int n, int h, int w, int c, float* sums,
                       void* hip_stream);
+
+/* *slot = max(*slot, max |x|) over c channels of a plane tensor; *slot must start at a non-negative value (0).
+ * The activation statistic of the int8 calibration (the "normal" max algorithm of the reference's quantiser,
+ * realesrgan/rknn/python/convert.py:215-230). */
+int srmi_absmax(const srmi_tensor_t* x, int n, int h, int w, int c, float* slot, void* hip_stream);
 
 /* Standalone coalesced permutes on plane tensors (same dtype in and out):
  * nn.PixelShuffle(r) (edsr_model.py:57,67; rcan_model.py:44,51) and
@@ -298,6 +313,23 @@ int srmi_model_set_lanes(srmi_model_t* m, int lanes);
  * result stays within the half-precision parity bound (u8 diff <= 1 LSB, PSNR >= 50 dB); 0 gives
  * plain f16 everywhere. */
 int srmi_model_set_growth_round8(srmi_model_t* m, int on);
+/*
+ * w8a8 mode of RRDBNet (f16 models): the reference's low-precision deployment (realesrgan/rknn/python/convert.py:198-278,
+ * quantized_dtype w8a8 with a calibration set of [0,1] NCHW images) on the int8 matrix cores.
+ *   srmi_model_calibrate_begin(m);  srmi_model_forward_f32 / _u8 on the calibration images (any number of calls);
+ *   srmi_model_calibrate_end(m)     -> per-tensor activation scales (max |x| / 127) of every dense-block tensor, int8
+ *                                      weights per output channel (activation scales folded in), w8a8 switched on.
+ * In w8a8 mode the 15 convolutions of every RRDB (realesrgan_model.py:13-49) read int8 activations and weights and
+ * accumulate in int32; the residual trunk stays in half precision beside its quantised copy, and the layers
+ * outside the blocks (conv_first, conv_body, upsampling, conv_hr, conv_last) stay f16.  srmi_model_set_w8a8 switches
+ * between the two forms of a calibrated model.
+ */
+int srmi_model_calibrate_begin(srmi_model_t* m);
+int srmi_model_calibrate_end(srmi_model_t* m);
+int srmi_model_set_w8a8(srmi_model_t* m, int on);
+/* Number of calibrated tensors and their max |x| (order: per dense block, trunk input then x1..x4). */
+int srmi_model_calibration(const srmi_model_t* m, float* absmax, int capacity);
+
 /* Algorithmic conv FLOPs (2*Cin*Cout*9 per output pixel of every conv) of one forward at
  * (h, w) input size. */
 double srmi_model_flops(const srmi_model_t* m, int h, int w);

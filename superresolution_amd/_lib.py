@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SRMI_LIB points diagnostic runs at another build of the same library (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SRMI_LIB") or os.path.join(_HERE, "libsrmi355.so")
 
-F32, F16, BF16 = 0, 1, 2
+F32, F16, BF16, I8 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 ROUND_HALF_EVEN, ROUND_HALF_UP, ROUND_TRUNC = 0, 1, 2
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
@@ -28,7 +28,7 @@ class SrmiError(RuntimeError):
 
 class Tensor(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("img_stride", C.c_int64), ("plane_stride", C.c_int64),
-                ("dtype", C.c_int32), ("flags", C.c_int32)]
+                ("dtype", C.c_int32), ("flags", C.c_int32), ("qscale", C.c_float), ("reserved", C.c_int32)]
 
 
 TENSOR_ROUND8 = 1
@@ -45,7 +45,7 @@ class ConvDesc(C.Structure):
                 ("chansum", C.c_void_p), ("tail_out", C.c_void_p),
                 ("tail_mat", C.c_float * 9), ("tail_bias", C.c_float * 3),
                 ("tail_lo", C.c_float), ("tail_hi", C.c_float), ("tail_scale", C.c_float),
-                ("tail_round", C.c_int32)]
+                ("tail_round", C.c_int32), ("wscale", C.c_void_p)]
 
 
 class ConvFirstDesc(C.Structure):
@@ -72,7 +72,8 @@ EXPORTS = [
     "srmi_model_create", "srmi_model_destroy", "srmi_model_set_tensor", "srmi_model_num_keys",
     "srmi_model_key", "srmi_model_finalize", "srmi_model_forward_f32", "srmi_model_forward_u8",
     "srmi_model_workspace_bytes", "srmi_model_set_sweep", "srmi_model_set_lanes", "srmi_model_set_growth_round8", "srmi_model_flops", "srmi_model_set_rgb_shift",
-    "srmi_model_reserve", "srmi_model_forward_u8_host", "srmi_model_reserve_host",
+    "srmi_absmax", "srmi_model_calibrate_begin", "srmi_model_calibrate_end", "srmi_model_set_w8a8",
+    "srmi_model_calibration", "srmi_model_reserve", "srmi_model_forward_u8_host", "srmi_model_reserve_host",
     "srmi_model_forward_u8_noalloc", "srmi_static_workspace_bytes",
     "edsr_init", "edsr_release", "edsr_inference", "edsr_inference_ex",
     "rcan_init", "rcan_release", "rcan_inference", "rcan_inference_ex",
@@ -134,6 +135,12 @@ def lib():
                                                     C.c_int, C.c_int, C.c_void_p]
         L.srmi_model_forward_u8_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.srmi_model_reserve_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        if hasattr(L, "srmi_model_calibrate_begin"):  # (absent from older builds loaded through $SRMI_LIB)
+            L.srmi_absmax.argtypes = [C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            L.srmi_model_calibrate_begin.argtypes = [C.c_void_p]
+            L.srmi_model_calibrate_end.argtypes = [C.c_void_p]
+            L.srmi_model_set_w8a8.argtypes = [C.c_void_p, C.c_int]
+            L.srmi_model_calibration.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.srmi_model_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.srmi_static_workspace_bytes.argtypes = []
         L.srmi_static_workspace_bytes.restype = C.c_size_t

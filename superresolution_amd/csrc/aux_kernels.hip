@@ -206,6 +206,36 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(TView x, long long hw
     }
 }
 
+// max |x| over c channels of a plane tensor (calibration of the int8 path).  Non-negative floats order like their
+// bit patterns, so one integer atomic max per workgroup folds the result into *slot (which accumulates over calls).
+__global__ __launch_bounds__(256) void absmax_kernel(TView x, int n_img, long long hw, int c, unsigned* slot) {
+    const int groups = c >> 3;
+    const long long total = (long long)n_img * hw * groups;
+    float m = 0.f;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int sub = (int)(idx & 1);
+        long long t = idx >> 1;
+        const long long pix = t % hw;
+        t /= hw;
+        const int pairs = groups >> 1;
+        const int g = (int)(t % pairs) * 2 + sub;
+        const int n = (int)(t / pairs);
+        float v[8];
+        load8(x, n, pix, g * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m == m) atomicMax(slot, __float_as_uint(m));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Permutes.  One thread = one output pixel x one 16-byte chunk.
 // ------------------------------------------------------------------------------------------------
@@ -401,6 +431,16 @@ extern "C" int srmi_channel_sums(const srmi_tensor_t* x, int n, int h, int w, in
     seg = (seg + 127) / 128 * 128;
     dim3 grid((unsigned)((hw + seg - 1) / seg), (unsigned)spans, (unsigned)n);
     hipLaunchKernelGGL(channel_sums_kernel, grid, dim3(256), 0, s, to_view(*x), hw, c, sums, (int)seg);
+    SRMI_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int srmi_absmax(const srmi_tensor_t* x, int n, int h, int w, int c, float* slot, void* hip_stream) {
+    if (!x || !x->ptr || !slot) SRMI_FAIL("srmi_absmax: null pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 16) SRMI_FAIL("srmi_absmax: bad shape (c must be a multiple of 16)");
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n * hw * (c / 8), 256, 1024)), dim3(256), 0, (hipStream_t)hip_stream,
+                       to_view(*x), n, hw, c, (unsigned*)slot);
     SRMI_HIP(hipGetLastError());
     return 0;
 }

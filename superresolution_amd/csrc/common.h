@@ -31,13 +31,14 @@ struct TView {
     long long plane_stride_b;
     int dtype;
     int flags;  // SRMI_TENSOR_* bits
+    float qscale;  // SRMI_I8: q = clamp(rint(value * qscale), -127, 127)
 };
 
-static inline int dtype_size(int dt) { return dt == SRMI_F32 ? 4 : 2; }
+static inline int dtype_size(int dt) { return dt == SRMI_F32 ? 4 : dt == SRMI_I8 ? 1 : 2; }
 // One plane holds kPixBytes bytes of channels per pixel (16 halves or 8 floats): one LDS-DMA stage of the
 // conv kernel reads whole planes, so every fetched cache line is used in full.
 constexpr int kPixBytes = 32;
-static inline int dtype_cpb(int dt) { return dt == SRMI_F32 ? 8 : 16; }  // channels per plane
+static inline int dtype_cpb(int dt) { return dt == SRMI_F32 ? 8 : dt == SRMI_I8 ? 32 : 16; }  // channels per plane
 
 static inline TView to_view(const srmi_tensor_t& t) {
     TView v;
@@ -46,6 +47,7 @@ static inline TView to_view(const srmi_tensor_t& t) {
     v.plane_stride_b = (long long)t.plane_stride * dtype_size(t.dtype);
     v.dtype = t.dtype;
     v.flags = t.flags;
+    v.qscale = t.qscale;
     return v;
 }
 
@@ -67,6 +69,7 @@ struct ConvParams {
     TView in;
     const char* wpk;
     const float* bias;
+    const float* wscale;  // SRMI_I8: per-output-channel dequantisation scale (packed order), else null
     float alpha, beta;
     TView res1, res2, out, out2;
     float* chansum;

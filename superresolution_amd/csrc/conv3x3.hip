@@ -48,6 +48,9 @@
 
 namespace srmi {
 
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 template <int DT>
 __device__ __forceinline__ void mma_chunk(f32x16& c, const u32x4& wfrag, const u32x4& pfrag) {
     if constexpr (DT == SRMI_F16) {
@@ -56,6 +59,12 @@ __device__ __forceinline__ void mma_chunk(f32x16& c, const u32x4& wfrag, const u
     } else if constexpr (DT == SRMI_BF16) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag),
                                                     __builtin_bit_cast(bf16x8, pfrag), c, 0, 0, 0);
+    } else if constexpr (DT == SRMI_I8) {
+        // int8 operands, exact int32 accumulation: one instruction multiplies the 32 input channels of a plane
+        // (16 bytes per lane half).  The accumulator registers are shared with the float paths bit for bit.
+        c = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wfrag),
+                                                                             __builtin_bit_cast(i32x4, pfrag),
+                                                                             __builtin_bit_cast(i32x16, c), 0, 0, 0));
     } else {
         // whole-vector casts first: bit-casting a single element of a vector reference makes
         // hipcc (ROCm 7.2) read element 0 for every j
@@ -121,6 +130,8 @@ __device__ __forceinline__ void ld8(const TView& t, int n, long long pix, int c,
         const f32x4 x0 = *(const f32x4*)a, x1 = *(const f32x4*)(a + 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+    } else if constexpr (TYPE == SRMI_I8) {
+        load8(t, n, pix, c, v);
     } else {
         const char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 32 + (c & 15) * 2;
         if constexpr (TYPE == SRMI_F16) {
@@ -144,6 +155,9 @@ __device__ __forceinline__ void st8(const TView& t, int n, long long pix, int c,
         const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
         *(f32x4*)a = x0;
         *(f32x4*)(a + 16) = x1;
+    } else if constexpr (TYPE == SRMI_I8) {
+        char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 5) * t.plane_stride_b + pix * 32 + (c & 31);
+        *(u32x2*)a = quant8_i8(v, t.qscale);
     } else {
         char* a = t.ptr + (long long)n * t.img_stride_b + (long long)(c >> 4) * t.plane_stride_b + pix * 32 + (c & 15) * 2;
         if constexpr (TYPE == SRMI_F16) {
@@ -195,6 +209,19 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
 #pragma unroll
             for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
         }
+    // int8 compute: per-output-channel dequantisation scales, laid out like the bias
+    float scale_r[DT == SRMI_I8 ? NB : 1][2][8];
+    if constexpr (DT == SRMI_I8) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float* sp = lds_bias + 32 * NB + b * 32 + 16 * q + 8 * k.lh;
+                const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { scale_r[b][q][j] = s0[j]; scale_r[b][q][4 + j] = s1[j]; }
+            }
+    }
     float csum[NB][2][8];
     if (p.chansum) {
 #pragma unroll
@@ -261,8 +288,13 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r][b][8 * q + j]),
                                                                      __float_as_uint(acc[r][b][8 * q + 4 + j]),
                                                                      false, false);
-                    v[b][q][j] = __uint_as_float(sw[0]) + bias_r[b][q][j];
-                    v[b][q][4 + j] = __uint_as_float(sw[1]) + bias_r[b][q][4 + j];
+                    if constexpr (DT == SRMI_I8) {
+                        v[b][q][j] = (float)(int)sw[0] * scale_r[b][q][j] + bias_r[b][q][j];
+                        v[b][q][4 + j] = (float)(int)sw[1] * scale_r[b][q][4 + j] + bias_r[b][q][4 + j];
+                    } else {
+                        v[b][q][j] = __uint_as_float(sw[0]) + bias_r[b][q][j];
+                        v[b][q][4 + j] = __uint_as_float(sw[1]) + bias_r[b][q][4 + j];
+                    }
                 }
             }
         if (p.act == SRMI_ACT_RELU) {
@@ -571,6 +603,8 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
     issue(0, 0);
     // this thread's bias value waits in a register until the stage buffers are free
     const float bias_v = tid < 32 * NB ? p.bias[ct * 32 * NB + tid] : 0.f;
+    float scale_v = 0.f;
+    if constexpr (DT == SRMI_I8) scale_v = tid < 32 * NB ? p.wscale[ct * 32 * NB + tid] : 0.f;
     if (G::NS == 3 && nstage > 1) issue(1, 1);
     STAMP();
 
@@ -773,7 +807,10 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
 #ifdef SRMI_STAMPS_EPI
     STAMP();
 #endif
-    if (tid < 32 * NB) ((float*)(smem + G::BIAS_OFFSET))[tid] = bias_v;
+    if (tid < 32 * NB) {
+        ((float*)(smem + G::BIAS_OFFSET))[tid] = bias_v;
+        if constexpr (DT == SRMI_I8) ((float*)(smem + G::BIAS_OFFSET))[32 * NB + tid] = scale_v;
+    }
     __syncthreads();
 #ifdef SRMI_STAMPS_EPI
     STAMP();
@@ -788,6 +825,19 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
     const int od = p.out.ptr ? p.out.dtype : -1, rd = p.res1.ptr ? p.res1.dtype : -1;
     const int r2 = p.res2.ptr ? p.res2.dtype : -1, o2 = p.out2.ptr ? p.out2.dtype : -1;
     const bool plain_io = p.tail_mode == SRMI_TAIL_NONE && od == DT && (r2 == -1 || r2 == rd);
+    if constexpr (DT == SRMI_I8) {
+        // int8 dense blocks: grown channels go out as int8; the block's last conv adds the half-precision trunk
+        // and writes the new trunk twice, quantised (next conv input) and in half precision (next residual)
+        if (plain_io && rd == -1 && o2 == -1) {
+            epilogue<DT, MB, NB, DT, -1, false, -1>(p, ctx, acc, lds_bias, lds_red);
+        } else if (plain_io && rd == SRMI_F16 && r2 == -1 && o2 == SRMI_F16) {
+            epilogue<DT, MB, NB, DT, SRMI_F16, false, SRMI_F16>(p, ctx, acc, lds_bias, lds_red);
+        } else if (plain_io && rd == SRMI_F16 && r2 == SRMI_F16 && o2 == SRMI_F16) {
+            epilogue<DT, MB, NB, DT, SRMI_F16, true, SRMI_F16>(p, ctx, acc, lds_bias, lds_red);
+        } else {
+            epilogue<DT, MB, NB, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc, lds_bias, lds_red);
+        }
+    } else {
     if (plain_io && rd == -1 && o2 == -1) {
         epilogue<DT, MB, NB, DT, -1, false, -1>(p, ctx, acc, lds_bias, lds_red);
     } else if (plain_io && rd == SRMI_F32 && r2 == -1 && o2 == -1) {
@@ -804,6 +854,7 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
         epilogue<DT, MB, NB, DT, DT, true, DT>(p, ctx, acc, lds_bias, lds_red);
     } else {
         epilogue<DT, MB, NB, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc, lds_bias, lds_red);
+    }
     }
     STAMP();
 #ifdef SRMI_CLOCK
@@ -846,6 +897,10 @@ static int launch(const ConvParams& p, hipStream_t stream) {
 
 template <int DT>
 static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
+    if constexpr (DT == SRMI_I8) {  // dense-block shapes only: 32-wide output tiles, 8- or 12-row tiles
+        if (nb != 1 || mb == 4) SRMI_FAIL("srmi_conv3x3: int8 needs cout_tile 32 and rows_per_wave 2 or 3");
+        return mb == 2 ? launch<DT, 2, 1>(p, s) : launch<DT, 3, 1>(p, s);
+    }
     if (nb == 1) {
         if (mb == 2) return launch<DT, 2, 1>(p, s);
         if (mb == 3) return launch<DT, 3, 1>(p, s);
@@ -858,6 +913,7 @@ static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
 
 template <int DT>
 static int configure_dt() {
+    if constexpr (DT == SRMI_I8) return configure<DT, 2, 1>() || configure<DT, 3, 1>();
     return configure<DT, 2, 1>() || configure<DT, 3, 1>() || configure<DT, 4, 1>() || configure<DT, 2, 2>() ||
            configure<DT, 3, 2>();
 }
@@ -871,7 +927,7 @@ using namespace srmi;
 // Sets the kernel attributes of every instantiation on the current device, so that later launches on it
 // (for instance under stream capture) consist of the launch alone.
 int srmi_conv3x3_prepare_device() {
-    return (configure_dt<SRMI_F16>() || configure_dt<SRMI_BF16>() || configure_dt<SRMI_F32>()) ? -1 : 0;
+    return (configure_dt<SRMI_F16>() || configure_dt<SRMI_BF16>() || configure_dt<SRMI_F32>() || configure_dt<SRMI_I8>()) ? -1 : 0;
 }
 
 extern "C" int srmi_conv3x3_tiles(int h, int w, int rows_per_wave) {
@@ -882,8 +938,14 @@ extern "C" int srmi_conv3x3_tiles(int h, int w, int rows_per_wave) {
 
 extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     if (!d) SRMI_FAIL("srmi_conv3x3: null descriptor");
-    if (d->dtype != SRMI_F32 && d->dtype != SRMI_F16 && d->dtype != SRMI_BF16)
+    if (d->dtype != SRMI_F32 && d->dtype != SRMI_F16 && d->dtype != SRMI_BF16 && d->dtype != SRMI_I8)
         SRMI_FAIL("srmi_conv3x3: bad dtype %d", d->dtype);
+    if (d->dtype == SRMI_I8) {
+        if (!d->wscale) SRMI_FAIL("srmi_conv3x3: int8 compute needs wscale");
+        if (d->tail_mode != SRMI_TAIL_NONE || d->ps_r > 1 || d->chansum || d->cout_tile != 32)
+            SRMI_FAIL("srmi_conv3x3: int8 compute supports plain convolutions with cout_tile 32 only");
+        if (d->out.ptr && d->out.dtype == SRMI_I8 && !(d->out.qscale > 0.f)) SRMI_FAIL("srmi_conv3x3: int8 output needs a positive qscale");
+    }
     const int cpb = dtype_cpb(d->dtype);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0) SRMI_FAIL("srmi_conv3x3: bad shape n=%d h=%d w=%d", d->n, d->h, d->w);
     if (d->cin <= 0 || d->cin % cpb) SRMI_FAIL("srmi_conv3x3: cin=%d is not a multiple of %d", d->cin, cpb);
@@ -927,6 +989,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
         p.in_plane_bytes = (unsigned)(src_px * kPixBytes);
     }
     p.wpk = (const char*)d->wpk; p.bias = d->bias;
+    p.wscale = d->wscale;
     p.alpha = d->alpha; p.beta = d->beta;
     p.res1 = to_view(d->res1); p.res2 = to_view(d->res2);
     p.out = to_view(d->out); p.out2 = to_view(d->out2);
@@ -948,5 +1011,6 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     const int nb = d->cout_tile / 32;
     if (d->dtype == SRMI_F16) return launch_dt<SRMI_F16>(p, mb, nb, s);
     if (d->dtype == SRMI_BF16) return launch_dt<SRMI_BF16>(p, mb, nb, s);
+    if (d->dtype == SRMI_I8) return launch_dt<SRMI_I8>(p, mb, nb, s);
     return launch_dt<SRMI_F32>(p, mb, nb, s);
 }

@@ -48,6 +48,7 @@ struct HostTensor {
 struct ConvW {
     void* wpk = nullptr;
     float* bias = nullptr;
+    float* wscale = nullptr;  // int8 convs: per-output-channel dequantisation scale
     int cout = 0, cin = 0, cout_tile = 0, ps_r = 1;
 };
 
@@ -109,6 +110,20 @@ struct srmi_model {
     hipEvent_t last_done = nullptr;
     bool has_last_done = false;
     char* static_ws = nullptr;  // this device's copy of `scratch` (resolved in srmi_model_finalize)
+
+    // w8a8 mode (RRDBNet): calibration statistics and the int8 form of the dense-block convs.
+    // Slot 5*g + j holds max |x| of tensor j of dense block g (j = 0: the block's trunk input, 1..4: x1..x4);
+    // block 3*num_block is the trunk behind the last block.
+    bool calibrating = false, calibrated = false, w8a8 = false;
+    float* calib_dev = nullptr;
+    std::vector<float> absmax;
+    std::map<std::string, ConvW> convs_q;
+    std::vector<void*> dev_allocs_q;
+    int calib_slots() const { return 5 * (3 * d.n_blocks + 1); }
+    float act_scale(int g, int j) const {
+        const float a = absmax[5 * g + j];
+        return a > 0.f ? a / 127.f : 1.f;
+    }
 
     // Host-buffer path (srmi_model_forward_u8_host): one slot per lane = pinned staging + device images
     struct HostSlot {
@@ -350,6 +365,36 @@ struct Exec {
         return srmi_conv3x3(&d, stream);
     }
 
+    // int8 form of a dense-block conv (w8a8 mode)
+    int conv_q(const std::string& name, const srmi_tensor_t& in, int h, int w, int act, float alpha,
+               const srmi_tensor_t* res1, float beta, const srmi_tensor_t* res2, const srmi_tensor_t* out,
+               const srmi_tensor_t* out2) {
+        auto it = m->convs_q.find(name);
+        if (it == m->convs_q.end()) SRMI_FAIL("internal: int8 conv '%s' not prepared", name.c_str());
+        const ConvW& cw = it->second;
+        srmi_conv_desc_t d;
+        memset(&d, 0, sizeof(d));
+        d.dtype = SRMI_I8;
+        d.n = ns; d.h = h; d.w = w;
+        d.cin = cw.cin; d.cout = cw.cout;
+        d.act = act; d.ps_r = 1; d.cout_tile = cw.cout_tile;
+        d.rows_per_wave = pick_rows_per_wave(m, h);
+        d.in = in;
+        d.wpk = cw.wpk; d.bias = cw.bias; d.wscale = cw.wscale;
+        d.alpha = alpha; d.beta = beta;
+        if (res1) d.res1 = *res1;
+        if (res2) d.res2 = *res2;
+        if (out) d.out = *out;
+        if (out2) d.out2 = *out2;
+        return srmi_conv3x3(&d, stream);
+    }
+
+    // calibration: fold max |x| of a freshly written tensor into its slot
+    int observe(const srmi_tensor_t& t, int h, int w, int c, int slot) {
+        if (!m->calibrating) return 0;
+        return srmi_absmax(&t, ns, h, w, c, m->calib_dev + slot, stream);
+    }
+
     int tail(const std::string& name, const srmi_tensor_t& in, int h, int w, int mode, void* dst,
              const float* mat, const float* bias, float lo, float hi, float scale, int round) {
         const ConvW& cw = m->convs[name];
@@ -424,6 +469,7 @@ static int run_rrdbnet(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int 
     {
         srmi_tensor_t o = tv(D[0]), o2 = tv(F);
         if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
+        if (ex->observe(o, h, w, nf, 0)) return -1;
     }
     int k = 0;  // dense buffer holding the current trunk in channels [0, nf)
     char name[96];
@@ -436,6 +482,7 @@ static int run_rrdbnet(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int 
                 srmi_tensor_t o = tv(D[k], nf + (j - 1) * gc);
                 if (m->growth_round8 && T == SRMI_F16) o.flags = SRMI_TENSOR_ROUND8;
                 if (ex->conv(name, in, h, w, SRMI_ACT_LRELU, false, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+                if (ex->observe(o, h, w, gc, 5 * (3 * i + r - 1) + j)) return -1;
             }
             snprintf(name, sizeof(name), "body.%d.rdb%d.conv5", i, r);
             // residual x of this RDB: the RRDB input for rdb1, else the previous RDB's output
@@ -451,6 +498,7 @@ static int run_rrdbnet(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int 
                 const srmi_tensor_t o2 = tv(R[(i + 1) & 1]);
                 if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 0.2f, &res1, 0.2f, &res2, &o, &o2)) return -1;
             }
+            if (ex->observe(o, h, w, nf, 5 * (3 * i + r))) return -1;
             k ^= 1;
         }
     }
@@ -477,6 +525,140 @@ static int run_rrdbnet(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int 
     }
     return ex->tail("conv_last", tv(U3), hh, ww, io->tail_mode, io->out, io->post_mat, io->post_bias,
                     io->lo, io->hi, io->scale, io->round);
+}
+
+// RRDBNet in w8a8 mode: the dense blocks on the int8 matrix cores.  The dense buffer holds int8 planes of 32
+// channels (x in planes 0-1, x1..x4 in planes 2..5, each tensor with its calibrated scale); every block's last
+// conv adds the half-precision trunk and writes the new trunk twice: quantised into the other dense buffer (the
+// next block's conv input) and in f16 (the next residual), so quantisation noise never accumulates along the
+// residual chain.  Everything outside the blocks runs as in the f16 plan.
+static int run_rrdbnet_w8a8(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, int w) {
+    const auto& d = m->d;
+    const int nf = d.n_feats, gc = d.grow_ch, TH = SRMI_F16;
+    Buf D[2] = {A.take(nf + 4 * gc, h, w, SRMI_I8), A.take(nf + 4 * gc, h, w, SRMI_I8)};
+    Buf R[2] = {A.take(nf, h, w, TH), A.take(nf, h, w, TH)};
+    Buf X[2] = {A.take(nf, h, w, TH), A.take(nf, h, w, TH)};
+    Buf F = A.take(nf, h, w, TH);
+    Buf FE = A.take(nf, h, w, TH);
+    const int up = d.scale == 4 ? 2 : 1;
+    Buf U1 = A.take(nf, 2 * h, 2 * w, TH);
+    Buf U2, U3;
+    const int hh = h * d.scale, ww = w * d.scale;
+    if (up == 2) U2 = A.take(nf, hh, ww, TH);
+    U3 = A.take(nf, hh, ww, TH);
+    if (!ex) return 0;
+    auto qt = [&](const Buf& b, int c0, int g, int j) {
+        srmi_tensor_t t = tv(b, c0);
+        t.qscale = 1.0f / m->act_scale(g, j);
+        return t;
+    };
+    {
+        srmi_tensor_t o = qt(D[0], 0, 0, 0), o2 = tv(F);
+        if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
+    }
+    int k = 0;
+    char name[96];
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const Buf& Rin = i == 0 ? F : R[i & 1];
+        for (int r = 1; r <= 3; ++r) {
+            const int g = 3 * i + r - 1;
+            const srmi_tensor_t in = qt(D[k], 0, g, 0);
+            for (int j = 1; j <= 4; ++j) {
+                snprintf(name, sizeof(name), "body.%d.rdb%d.conv%d", i, r, j);
+                const srmi_tensor_t o = qt(D[k], nf + (j - 1) * gc, g, j);
+                if (ex->conv_q(name, in, h, w, SRMI_ACT_LRELU, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+            }
+            snprintf(name, sizeof(name), "body.%d.rdb%d.conv5", i, r);
+            const srmi_tensor_t res1 = r == 1 ? tv(Rin) : tv(X[r & 1]);
+            const srmi_tensor_t o = qt(D[k ^ 1], 0, g + 1, 0);
+            if (r < 3) {
+                const srmi_tensor_t o2 = tv(X[(r + 1) & 1]);
+                if (ex->conv_q(name, in, h, w, SRMI_ACT_NONE, 0.2f, &res1, 1.f, nullptr, &o, &o2)) return -1;
+            } else {
+                const srmi_tensor_t res2 = tv(Rin), o2 = tv(R[(i + 1) & 1]);
+                if (ex->conv_q(name, in, h, w, SRMI_ACT_NONE, 0.2f, &res1, 0.2f, &res2, &o, &o2)) return -1;
+            }
+            k ^= 1;
+        }
+    }
+    {
+        const srmi_tensor_t in = tv(R[d.n_blocks & 1]), res = tv(F), o = tv(FE);
+        if (ex->conv("conv_body", in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o, nullptr)) return -1;
+    }
+    {
+        const srmi_tensor_t in = tv(FE), o = tv(U1);
+        if (ex->conv("conv_up1", in, 2 * h, 2 * w, SRMI_ACT_LRELU, true, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+    }
+    Buf last = U1;
+    if (up == 2) {
+        const srmi_tensor_t in = tv(U1), o = tv(U2);
+        if (ex->conv("conv_up2", in, hh, ww, SRMI_ACT_LRELU, true, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+        last = U2;
+    }
+    {
+        const srmi_tensor_t in = tv(last), o = tv(U3);
+        if (ex->conv("conv_hr", in, hh, ww, SRMI_ACT_LRELU, false, 1.f, nullptr, 1.f, nullptr, &o, nullptr)) return -1;
+    }
+    return ex->tail("conv_last", tv(U3), hh, ww, io->tail_mode, io->out, io->post_mat, io->post_bias,
+                    io->lo, io->hi, io->scale, io->round);
+}
+
+// Int8 weights of the dense blocks from the calibrated activation scales: the scale of each input tensor is
+// folded into its weight columns, then every output channel is quantised symmetrically to [-127, 127]
+// (per-channel weight scales, the usual w8a8 recipe; realesrgan/rknn/python/convert.py:198-230 leaves this to the
+// vendor quantiser).
+static int prepare_w8a8(srmi_model* m) {
+    const auto& d = m->d;
+    const int nf = d.n_feats, gc = d.grow_ch;
+    for (void* p : m->dev_allocs_q) (void)hipFree(p);
+    m->dev_allocs_q.clear();
+    m->convs_q.clear();
+    auto upload = [&](const void* host, size_t bytes, void** out) -> int {
+        void* p = nullptr;
+        SRMI_HIP(hipMalloc(&p, bytes));
+        m->dev_allocs_q.push_back(p);
+        SRMI_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+        *out = p;
+        return 0;
+    };
+    char name[96];
+    for (int i = 0; i < d.n_blocks; ++i)
+        for (int r = 1; r <= 3; ++r)
+            for (int j = 1; j <= 5; ++j) {
+                snprintf(name, sizeof(name), "body.%d.rdb%d.conv%d", i, r, j);
+                const HostTensor& w = m->tensors[std::string(name) + ".weight"];
+                const HostTensor& b = m->tensors[std::string(name) + ".bias"];
+                const int g = 3 * i + r - 1, cout = (int)w.shape[0], cin = (int)w.shape[1];
+                std::vector<float> wq(w.data.size()), ws(cout);
+                for (int o = 0; o < cout; ++o) {
+                    float amax = 0.f;
+                    for (int c = 0; c < cin; ++c) {
+                        const float sa = m->act_scale(g, c < nf ? 0 : (c - nf) / gc + 1);
+                        for (int t = 0; t < 9; ++t) {
+                            const float v = w.data[((size_t)o * cin + c) * 9 + t] * sa;
+                            wq[((size_t)o * cin + c) * 9 + t] = v;
+                            amax = fmaxf(amax, fabsf(v));
+                        }
+                    }
+                    const float sw = amax > 0.f ? amax / 127.f : 1.f;
+                    ws[o] = sw;
+                    for (size_t e = (size_t)o * cin * 9; e < (size_t)(o + 1) * cin * 9; ++e) wq[e] = rintf(wq[e] / sw);
+                }
+                ConvW cw;
+                cw.cout = cout; cw.cin = cin; cw.cout_tile = 32; cw.ps_r = 1;
+                int nbias = 0;
+                const size_t bytes = srmi_pack_conv3x3_bytes(SRMI_I8, cout, cin, 32, &nbias);
+                if (!bytes) SRMI_FAIL("%s: shape [%d,%d,3,3] does not fit the int8 path (channels in multiples of 32)", name, cout, cin);
+                std::vector<char> wp(bytes);
+                std::vector<float> bp(nbias), sp(nbias, 0.f);
+                if (srmi_pack_conv3x3(SRMI_I8, cout, cin, 32, 1, wq.data(), b.data.data(), wp.data(), bp.data())) return -1;
+                for (int o = 0; o < cout; ++o) sp[o] = ws[o];
+                if (upload(wp.data(), bytes, &cw.wpk)) return -1;
+                if (upload(bp.data(), nbias * sizeof(float), (void**)&cw.bias)) return -1;
+                if (upload(sp.data(), nbias * sizeof(float), (void**)&cw.wscale)) return -1;
+                m->convs_q[name] = cw;
+            }
+    return 0;
 }
 
 // Upsampler + tail conv shared by EDSR and RCAN (edsr_model.py:50-77,105-108).
@@ -597,7 +779,8 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
 
 static int run_plan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, int w) {
     switch (m->d.arch) {
-        case SRMI_ARCH_RRDBNET: return run_rrdbnet(m, A, ex, io, h, w);
+        case SRMI_ARCH_RRDBNET:
+            return (m->w8a8 && !m->calibrating) ? run_rrdbnet_w8a8(m, A, ex, io, h, w) : run_rrdbnet(m, A, ex, io, h, w);
         case SRMI_ARCH_EDSR: return run_edsr(m, A, ex, io, h, w);
         case SRMI_ARCH_RCAN: return run_rcan(m, A, ex, io, h, w);
     }
@@ -929,6 +1112,8 @@ extern "C" void srmi_model_destroy(srmi_model_t* m) {
     if (m->fork) (void)hipEventDestroy(m->fork);
     if (m->last_done) (void)hipEventDestroy(m->last_done);
     free_host_slots(m);
+    for (void* p : m->dev_allocs_q) (void)hipFree(p);
+    if (m->calib_dev) (void)hipFree(m->calib_dev);
     delete m;
 }
 
@@ -968,6 +1153,8 @@ extern "C" int srmi_model_finalize(srmi_model_t* m) {
     m->dev_allocs.clear();
     m->convs.clear();
     m->cas.clear();
+    // new weights: an earlier calibration no longer applies
+    m->calibrated = m->w8a8 = m->calibrating = false;
     const auto& d = m->d;
     if (d.arch == SRMI_ARCH_RRDBNET) {
         if (upload_first(m, "conv_first")) return -1;
@@ -1124,6 +1311,56 @@ extern "C" int srmi_model_set_growth_round8(srmi_model_t* m, int on) {
     if (m->finalized) SRMI_FAIL("srmi_model_set_growth_round8: call before srmi_model_finalize (the weights are packed there)");
     m->growth_round8 = on != 0;
     return 0;
+}
+
+extern "C" int srmi_model_calibrate_begin(srmi_model_t* m) {
+    if (!m) SRMI_FAIL("srmi_model_calibrate_begin: null model");
+    if (!m->finalized) SRMI_FAIL("srmi_model_calibrate_begin: srmi_model_finalize has not been called");
+    if (m->d.arch != SRMI_ARCH_RRDBNET || m->d.dtype != SRMI_F16)
+        SRMI_FAIL("srmi_model_calibrate_begin: the w8a8 mode exists for RRDBNet models with f16 compute");
+    if (m->d.n_feats % 32 || m->d.grow_ch % 32) SRMI_FAIL("srmi_model_calibrate_begin: channel counts must be multiples of 32");
+    DeviceGuard guard;
+    if (guard.enter(m->d.device)) return -1;
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    const size_t bytes = (size_t)m->calib_slots() * sizeof(float);
+    if (!m->calib_dev) SRMI_HIP(hipMalloc((void**)&m->calib_dev, bytes));
+    SRMI_HIP(hipDeviceSynchronize());
+    SRMI_HIP(hipMemset(m->calib_dev, 0, bytes));
+    m->calibrating = true;
+    return 0;
+}
+
+extern "C" int srmi_model_calibrate_end(srmi_model_t* m) {
+    if (!m) SRMI_FAIL("srmi_model_calibrate_end: null model");
+    if (!m->calibrating) SRMI_FAIL("srmi_model_calibrate_end: srmi_model_calibrate_begin has not been called");
+    DeviceGuard guard;
+    if (guard.enter(m->d.device)) return -1;
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    SRMI_HIP(hipDeviceSynchronize());
+    m->absmax.assign(m->calib_slots(), 0.f);
+    SRMI_HIP(hipMemcpy(m->absmax.data(), m->calib_dev, m->absmax.size() * sizeof(float), hipMemcpyDeviceToHost));
+    m->calibrating = false;
+    if (!(m->absmax[0] > 0.f)) SRMI_FAIL("srmi_model_calibrate_end: no forward pass ran between begin and end");
+    if (prepare_w8a8(m)) return -1;
+    m->calibrated = true;
+    m->w8a8 = true;
+    return 0;
+}
+
+extern "C" int srmi_model_set_w8a8(srmi_model_t* m, int on) {
+    if (!m) SRMI_FAIL("srmi_model_set_w8a8: null model");
+    if (on && !m->calibrated) SRMI_FAIL("srmi_model_set_w8a8: the model has not been calibrated (srmi_model_calibrate_begin / _end)");
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    m->w8a8 = on != 0;
+    return 0;
+}
+
+extern "C" int srmi_model_calibration(const srmi_model_t* m, float* absmax, int capacity) {
+    if (!m || !m->calibrated) return 0;
+    const int n = (int)m->absmax.size();
+    if (absmax)
+        for (int i = 0; i < n && i < capacity; ++i) absmax[i] = m->absmax[i];
+    return n;
 }
 
 extern "C" int srmi_model_set_lanes(srmi_model_t* m, int lanes) {

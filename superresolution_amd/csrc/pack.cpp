@@ -2,10 +2,11 @@
 // stages with LDS-DMA.
 //
 // Packed layout: [cout tile][stage = (cin block, half)][tap = ky*3+kx][row = output channel within
-// tile][32 bytes] where the 32 bytes are the stage's input channels (16 halves or 8 floats) as two
+// tile][32 bytes] where the 32 bytes are the stage's input channels (16 halves, 8 floats or 32 int8) as two
 // 16-byte chunks, stored chunk index = logical chunk ^ ((row_in_image >> 3) & 1), row_in_image =
 // tap * cout_tile + row.  With pixel-shuffle packing the output channels are permuted so that a
 // 32-channel block holds one (i, j) sub-pixel position of 32 consecutive post-shuffle channels.
+#include <math.h>
 #include <string.h>
 
 #include <vector>
@@ -99,6 +100,10 @@ extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, in
                             const float v = o < 0 ? 0.f : w[((size_t)o * cin + ci) * 9 + tap];
                             if (dtype == SRMI_F32) {
                                 memcpy(dst + 4 * e, &v, 4);
+                            } else if (dtype == SRMI_I8) {
+                                // already quantised by the caller: integer-valued floats in [-127, 127]
+                                const long q = lrintf(v);
+                                dst[e] = (char)(signed char)(q < -127 ? -127 : q > 127 ? 127 : q);
                             } else {
                                 const uint16_t hv = dtype == SRMI_F16 ? f32_to_f16(v) : f32_to_bf16(v);
                                 memcpy(dst + 2 * e, &hv, 2);

@@ -90,6 +90,33 @@ class Engine:
         v = (C.c_float * 3)(*[float(x) for x in shift])
         check(lib().srmi_model_set_rgb_shift(self._h, v), "srmi_model_set_rgb_shift")
 
+    def calibrate(self, frames, batch=4):
+        """w8a8 calibration (RRDBNet, f16 compute): run `frames` (uint8 NHWC, or float32 NCHW in [0,1] as the
+        reference's calibration .npy files hold them, realesrgan/rknn/python/convert.py:198-213) through the network
+        while the activation ranges of the dense blocks are recorded, then switch the int8 mode on.  Returns the
+        recorded max |x| values."""
+        check(lib().srmi_model_calibrate_begin(self._h), "srmi_model_calibrate_begin")
+        try:
+            t = torch.as_tensor(frames)
+            for i in range(0, t.shape[0], batch):
+                part = t[i:i + batch].to(self.device)
+                if part.dtype == torch.uint8:
+                    self.forward_u8(part)
+                else:
+                    self.forward_f32(part)
+            torch.cuda.synchronize(self.device)
+        finally:
+            rc = lib().srmi_model_calibrate_end(self._h)
+        check(rc, "srmi_model_calibrate_end")
+        n = lib().srmi_model_calibration(self._h, None, 0)
+        a = np.zeros(n, dtype=np.float32)
+        lib().srmi_model_calibration(self._h, a.ctypes.data, n)
+        return a
+
+    def set_w8a8(self, on=True):
+        """Switch a calibrated model between its int8 dense blocks and plain f16."""
+        check(lib().srmi_model_set_w8a8(self._h, int(bool(on))), "srmi_model_set_w8a8")
+
     def workspace_bytes(self):
         return int(lib().srmi_model_workspace_bytes(self._h))
 

@@ -13,9 +13,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F32, F16, BF16, Tensor, check, lib
+from ._lib import F32, F16, BF16, I8, Tensor, check, lib
 
-_TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
+_TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16, I8: torch.int8}
 
 
 def _stream():
@@ -26,14 +26,15 @@ PIX_BYTES = 32  # bytes of channels per pixel in one plane
 
 
 def cpb(dtype):
-    return 8 if dtype == F32 else 16
+    return 8 if dtype == F32 else 32 if dtype == I8 else 16
 
 
 class Planes:
     """A plane-layout activation tensor on the GPU."""
 
-    def __init__(self, n, c, h, w, dtype, device="cuda", zero=False):
+    def __init__(self, n, c, h, w, dtype, device="cuda", zero=False, qscale=0.0):
         self.n, self.c, self.h, self.w, self.dtype = n, c, h, w, dtype
+        self.qscale = float(qscale)   # int8 tensors: stored q = clamp(rint(value * qscale), -127, 127)
         self.planes = (c + cpb(dtype) - 1) // cpb(dtype)
         shape = (n, self.planes, h, w, cpb(dtype))
         self.buf = (torch.zeros if zero else torch.empty)(shape, dtype=_TORCH_DT[dtype], device=device)
@@ -47,13 +48,14 @@ class Planes:
         t.img_stride = self.planes * self.h * self.w * PIX_BYTES // es
         t.plane_stride = self.h * self.w * PIX_BYTES // es
         t.dtype = self.dtype
+        t.qscale = self.qscale
         return t
 
     @staticmethod
-    def from_nchw(x: torch.Tensor, dtype):
+    def from_nchw(x: torch.Tensor, dtype, qscale=0.0):
         x = x.to(device="cuda", dtype=torch.float32).contiguous()
         n, c, h, w = x.shape
-        p = Planes(n, c, h, w, dtype)
+        p = Planes(n, c, h, w, dtype, qscale=qscale)
         v = p.view()
         check(lib().srmi_nchw_to_planes(x.data_ptr(), C.byref(v), n, c, h, w, _stream()), "nchw_to_planes")
         return p
@@ -72,7 +74,9 @@ _NULL = Tensor()
 class PackedConv:
     """Weights of one 3x3 convolution in the kernel's device format."""
 
-    def __init__(self, weight, bias, dtype, cout_tile=None, ps_r=1, device="cuda"):
+    def __init__(self, weight, bias, dtype, cout_tile=None, ps_r=1, device="cuda", wscale=None):
+        """dtype I8: `weight` holds integer values in [-127, 127] and `wscale` the per-output-channel factor the
+        int32 accumulator is multiplied with (weight scale * input activation scale)."""
         w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))
         cout, cin = w.shape[:2]
         assert w.shape[2:] == (3, 3)
@@ -90,14 +94,19 @@ class PackedConv:
                                       None if b is None else b.ctypes.data, wp.ctypes.data, bp.ctypes.data),
               "pack_conv3x3")
         self.host_w, self.host_b = wp, bp
+        self.s = None
         if device is not None:
             self.w = torch.from_numpy(wp).to(device)
             self.b = torch.from_numpy(bp).to(device)
+            if wscale is not None:
+                sp = np.zeros(nb.value, dtype=np.float32)
+                sp[:cout] = np.asarray(wscale, dtype=np.float32)
+                self.s = torch.from_numpy(sp).to(device)
 
 
 def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Planes = None,
             beta=1.0, res2: Planes = None, out: Planes = None, out_c0=0, out_dtype=None,
-            out2: Planes = None, chansum=False, rows_per_wave=0, tail=None, out_round8=False):
+            out2: Planes = None, chansum=False, rows_per_wave=0, tail=None, out_round8=False, out_qscale=0.0):
     """act(conv(x)+b)*alpha+res1 (*beta+res2) -> out (see srmi_conv3x3 in include/srmi355.h).
 
     tail: None, or dict(mode=TAIL_*, mat=3x3, bias=3, lo, hi, scale, round) for the RGB layer.
@@ -111,6 +120,7 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
     d.in_up2, d.act, d.ps_r, d.cout_tile, d.rows_per_wave = int(up2), act, pc.ps_r, pc.cout_tile, rows_per_wave
     d.inp = x.view()
     d.wpk, d.bias = pc.w.data_ptr(), pc.b.data_ptr()
+    d.wscale = pc.s.data_ptr() if pc.s is not None else None
     d.alpha, d.beta = alpha, beta
     d.res1 = res1.view() if res1 is not None else _NULL
     d.res2 = res2.view() if res2 is not None else _NULL
@@ -120,7 +130,7 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
     if tail is None:
         r = pc.ps_r
         if out is None:
-            out = Planes(n, pc.cout // (r * r), h * r, w * r, pc.dtype if out_dtype is None else out_dtype)
+            out = Planes(n, pc.cout // (r * r), h * r, w * r, pc.dtype if out_dtype is None else out_dtype, qscale=out_qscale)
         d.out = out.view(out_c0)
         if out_round8:
             d.out.flags = _lib.TENSOR_ROUND8

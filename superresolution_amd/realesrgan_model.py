@@ -68,6 +68,13 @@ class RRDBNet(HipModule):
         return dict(arch=_lib.ARCH_RRDBNET, scale=self.scale, n_feats=self.num_feat, n_blocks=self.num_block,
                     grow_ch=self.num_grow_ch, growth_round8=self._srmi_growth_round8)
 
+    def quantize_w8a8(self, calibration_frames, batch=4):
+        """Calibrate on `calibration_frames` (uint8 NHWC, or float32 NCHW in [0,1] like the reference's calibration
+        .npy files, realesrgan/rknn/python/convert.py:198-213) and run the dense blocks in int8 from now on (f16
+        compute only).  `self.engine().set_w8a8(False)` returns to plain f16.  Changing a parameter afterwards
+        discards the calibration."""
+        return self.engine().calibrate(calibration_frames, batch=batch)
+
 
 def infer_model_type(model_path):
     """(type, scale, num_block) from the checkpoint file name, with the reference's precedence:
