@@ -329,6 +329,9 @@ int srmi_model_calibrate_end(srmi_model_t* m);
 int srmi_model_set_w8a8(srmi_model_t* m, int on);
 /* Number of calibrated tensors and their max |x| (order: per dense block, trunk input then x1..x4). */
 int srmi_model_calibration(const srmi_model_t* m, float* absmax, int capacity);
+/* Install activation ranges recorded earlier (srmi_model_calibration) and switch w8a8 on: how a deployed model
+ * skips the calibration run, as the reference ships the already quantised .rknn file. */
+int srmi_model_set_calibration(srmi_model_t* m, const float* absmax, int n);
 
 /* Algorithmic conv FLOPs (2*Cin*Cout*9 per output pixel of every conv) of one forward at
  * (h, w) input size. */

@@ -1347,6 +1347,27 @@ extern "C" int srmi_model_calibrate_end(srmi_model_t* m) {
     return 0;
 }
 
+extern "C" int srmi_model_set_calibration(srmi_model_t* m, const float* absmax, int n) {
+    if (!m || !absmax) SRMI_FAIL("srmi_model_set_calibration: null argument");
+    if (!m->finalized) SRMI_FAIL("srmi_model_set_calibration: srmi_model_finalize has not been called");
+    if (m->d.arch != SRMI_ARCH_RRDBNET || m->d.dtype != SRMI_F16)
+        SRMI_FAIL("srmi_model_set_calibration: the w8a8 mode exists for RRDBNet models with f16 compute");
+    if (m->d.n_feats % 32 || m->d.grow_ch % 32) SRMI_FAIL("srmi_model_set_calibration: channel counts must be multiples of 32");
+    if (n != m->calib_slots()) SRMI_FAIL("srmi_model_set_calibration: %d values given, this network has %d calibrated tensors", n, m->calib_slots());
+    for (int i = 0; i < n; ++i)
+        if (!(absmax[i] >= 0.f) || absmax[i] > 3.0e38f) SRMI_FAIL("srmi_model_set_calibration: value %d is not a finite non-negative number", i);
+    DeviceGuard guard;
+    if (guard.enter(m->d.device)) return -1;
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    SRMI_HIP(hipDeviceSynchronize());
+    m->absmax.assign(absmax, absmax + n);
+    m->calibrating = false;
+    if (prepare_w8a8(m)) return -1;
+    m->calibrated = true;
+    m->w8a8 = true;
+    return 0;
+}
+
 extern "C" int srmi_model_set_w8a8(srmi_model_t* m, int on) {
     if (!m) SRMI_FAIL("srmi_model_set_w8a8: null model");
     if (on && !m->calibrated) SRMI_FAIL("srmi_model_set_w8a8: the model has not been calibrated (srmi_model_calibrate_begin / _end)");

@@ -119,6 +119,25 @@ static int load_model_body(FILE* f, long file_size, const char* path, int want_a
         SRMI_FAIL("%s is truncated or corrupt", path);
     }
     if (srmi_model_finalize(m)) { srmi_model_destroy(m); return -1; }
+    // optional trailer: activation ranges of a model calibrated for the int8 mode; SRMI_W8A8=0 ignores them
+    char tag[8];
+    int32_t nc = 0;
+    if (read_exact(f, tag, 8) && !memcmp(tag, "SRMIQ001", 8)) {
+        const char* q = getenv("SRMI_W8A8");
+        if (!read_exact(f, &nc, 4) || nc <= 0 || (long)nc * 4 > file_size - ftell(f)) {
+            srmi_model_destroy(m);
+            SRMI_FAIL("%s: corrupt calibration trailer", path);
+        }
+        std::vector<float> cal((size_t)nc);
+        if (!read_exact(f, cal.data(), sizeof(float) * (size_t)nc)) {
+            srmi_model_destroy(m);
+            SRMI_FAIL("%s: truncated calibration trailer", path);
+        }
+        if (!(q && !strcmp(q, "0")) && d.dtype == SRMI_F16 && srmi_model_set_calibration(m, cal.data(), nc)) {
+            srmi_model_destroy(m);
+            return -1;
+        }
+    }
     *out = m;
     *desc_out = d;
     return 0;

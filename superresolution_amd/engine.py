@@ -113,6 +113,19 @@ class Engine:
         lib().srmi_model_calibration(self._h, a.ctypes.data, n)
         return a
 
+    def calibration(self):
+        """max |x| of the calibrated tensors (empty array when the model is not calibrated)."""
+        n = lib().srmi_model_calibration(self._h, None, 0)
+        a = np.zeros(n, dtype=np.float32)
+        if n:
+            lib().srmi_model_calibration(self._h, a.ctypes.data, n)
+        return a
+
+    def set_calibration(self, absmax):
+        """Install recorded activation ranges (see calibration()) and switch the int8 mode on."""
+        a = np.ascontiguousarray(np.asarray(absmax, dtype=np.float32))
+        check(lib().srmi_model_set_calibration(self._h, a.ctypes.data, a.size), "srmi_model_set_calibration")
+
     def set_w8a8(self, on=True):
         """Switch a calibrated model between its int8 dense blocks and plain f16."""
         check(lib().srmi_model_set_w8a8(self._h, int(bool(on))), "srmi_model_set_w8a8")

@@ -2,7 +2,9 @@
 
 The reference runners load a vendor-compiled `.dla` blob (edsr.cpp:126-157); the MI355X runners
 load this container instead: the architecture hyper-parameters plus the state_dict tensors in the
-reference's key layout, float32 little endian ("SRMIW001", see csrc/runners.cpp).
+reference's key layout, float32 little endian ("SRMIW001", see csrc/runners.cpp).  A model calibrated for the int8
+mode carries its activation ranges in an optional trailer ("SRMIQ001", int32 count, float32 values): the runner
+then starts in w8a8 mode, as the reference's runner loads an already quantised .rknn file.
 """
 from __future__ import annotations
 
@@ -38,6 +40,13 @@ def save_weights(model, path):
             f.write(struct.pack("<i", a.ndim))
             f.write(struct.pack(f"<{a.ndim}q", *a.shape))
             f.write(a.tobytes())
+        # activation ranges of a calibrated model (only looked up when an engine already exists)
+        eng = getattr(model, "_srmi_engine", None)
+        cal = eng.calibration() if eng is not None and getattr(model, "_srmi_stamp", None) == model._param_stamp() else ()
+        if len(cal):
+            f.write(b"SRMIQ001")
+            f.write(struct.pack("<i", len(cal)))
+            f.write(np.asarray(cal, dtype="<f4").tobytes())
     return path
 
 
@@ -78,6 +87,10 @@ def load_weights(path, **engine_kwargs):
             dims = struct.unpack(f"<{nd}q", f.read(8 * nd))
             n = int(np.prod(dims)) if nd else 1
             sd[name] = torch.from_numpy(np.frombuffer(f.read(4 * n), dtype="<f4").reshape(dims).copy())
+        cal = None
+        if f.read(8) == b"SRMIQ001":
+            (nc,) = struct.unpack("<i", f.read(4))
+            cal = np.frombuffer(f.read(4 * nc), dtype="<f4").copy()
     if arch == _lib.ARCH_RRDBNET:
         model = RRDBNet(num_feat=nf, num_block=nb, num_grow_ch=gc, scale=scale, **engine_kwargs)
     elif arch == _lib.ARCH_EDSR:
@@ -89,4 +102,6 @@ def load_weights(path, **engine_kwargs):
     else:
         raise ValueError(f"{path}: unknown architecture {arch}")
     model.load_state_dict(sd, strict=True)
+    if cal is not None:
+        model.engine().set_calibration(cal)
     return model

@@ -116,3 +116,40 @@ def test_w8a8_needs_calibration_and_an_f16_rrdbnet():
     assert L.srmi_model_calibrate_end(eng._h) == -1 and b"no forward pass" in L.srmi_last_error()
     edsr, _ = H.build_model(dict(arch="edsr", n_resblocks=1, n_feats=64, scale=2, seed=84, input="range"), "f16")
     assert L.srmi_model_calibrate_begin(edsr.engine()._h) == -1
+
+
+def test_w8a8_weight_file_round_trip_and_runner(tmp_path):
+    """A calibrated model written by export.save_weights carries its activation ranges: the C runner and
+    export.load_weights start in w8a8 mode and give the calibrated model's bytes; SRMI_W8A8=0 gives plain f16."""
+    import ctypes as C
+    import os
+    from superresolution_amd import export
+    from tests.test_runner_gpu import RealesrganCtx, _take
+    L = _lib.lib()
+    meta = dict(arch="rrdbnet", num_block=1, scale=4, seed=85, input="unit")
+    model, _ = H.build_model(meta, "f16")
+    img = synth.smooth_image(339, 510, 86)
+    f16_out = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    model.quantize_w8a8(_calibration_frames(96, 128, 4))
+    want = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    assert not np.array_equal(want, f16_out)
+    path = str(tmp_path / "RealESRGAN_x4plus_w8a8.srmi")
+    export.save_weights(model, path)
+    again = export.load_weights(path, compute_dtype="f16")
+    assert np.array_equal(again.engine().calibration(), model.engine().calibration())
+    assert np.array_equal(again.forward_u8(img, _lib.ROUND_HALF_UP).numpy(), want)
+    for env, expect in ((None, want), ("0", f16_out)):
+        if env is None:
+            os.environ.pop("SRMI_W8A8", None)
+        else:
+            os.environ["SRMI_W8A8"] = env
+        try:
+            ctx = RealesrganCtx()
+            assert L.realesrgan_init(path.encode(), C.byref(ctx)) == 0, L.srmi_last_error()
+            out = C.c_void_p()
+            assert L.realesrgan_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), C.byref(out)) == 0
+            got = _take(out, 1356, 2040)
+            assert L.realesrgan_release(C.byref(ctx)) == 0
+        finally:
+            os.environ.pop("SRMI_W8A8", None)
+        assert np.array_equal(got, expect), f"SRMI_W8A8={env}"

@@ -8,10 +8,10 @@ O=$R/gpurun_out/$tag
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 -u $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/trace_default.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_lanes1 -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --lanes 1 > $O/trace_lanes1.log 2>&1
-timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 $R/bench.py --steps 1 --warmup 1 --batch 2 --lanes 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 $R/bench.py --steps 1 --warmup 1 --batch 2 --lanes 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-configs > $O/trace_default.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_lanes1 -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-configs --lanes 1 > $O/trace_lanes1.log 2>&1
+timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 $R/bench.py --steps 1 --warmup 1 --batch 2 --lanes 1 --no-cpu-baseline --no-side-configs > $O/pmc_fetch.log 2>&1
+timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 $R/bench.py --steps 1 --warmup 1 --batch 2 --lanes 1 --no-cpu-baseline --no-side-configs > $O/pmc_write.log 2>&1
 python3 $R/tools/pmc_summary.py $O/pmc_fetch srmi > $O/pmc_summary.txt
 python3 $R/tools/pmc_summary.py $O/pmc_write srmi >> $O/pmc_summary.txt
 cp $O/trace_default/*kernel_stats.csv $O/kernel_stats_default.csv
