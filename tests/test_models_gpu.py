@@ -287,3 +287,36 @@ def test_engine_rejects_bad_input():
     eng = model.engine()
     with pytest.raises(_lib.SrmiError):
         eng.load_state_dict({"not.a.key": np.zeros(3, np.float32)})
+
+
+@pytest.mark.parametrize("n_feats,scale", [(96, 2), (32, 3), (160, 4)])
+def test_edsr_widths_that_are_not_multiples_of_64(n_feats, scale):
+    """Feature counts that are multiples of 32 but not of 64 (and scale 3 with 32 features: a 288-channel upsampler
+    conv) run on 32-wide output tiles and match the oracle like every other shape."""
+    meta = dict(arch="edsr", n_resblocks=2, n_feats=n_feats, scale=scale, seed=91, input="range", n=1, h=19, w=27)
+    model, sd = H.build_model(meta, "f32")
+    x = H.input_for(meta)
+    y = model(x).numpy()
+    with torch.no_grad():
+        ref = H.oracle_forward(meta, sd, x).numpy()
+    err = np.abs(y - ref).max()
+    print(f"edsr n_feats={n_feats} x{scale}: max-abs {err:.3e}")
+    assert y.shape == (1, 3, 19 * scale, 27 * scale) and err <= H.f32_tol(meta)
+
+
+def test_caller_supplied_out_tensor_is_validated():
+    """`out=` goes to the kernels as a raw pointer: a tensor of another shape, type or layout must be refused."""
+    meta = dict(arch="rrdbnet", num_block=1, scale=4, seed=92, input="unit")
+    model, _ = H.build_model(meta, "f16")
+    eng = model.engine()
+    img = torch.from_numpy(synth.random_image(16, 24, 1, n=1)).cuda()
+    good = torch.empty((1, 64, 96, 3), dtype=torch.uint8, device="cuda")
+    assert eng.forward_u8(img, out=good) is good
+    for bad in (torch.empty((1, 64, 96, 4), dtype=torch.uint8, device="cuda")[..., :3],    # strided
+                torch.empty((1, 64, 95, 3), dtype=torch.uint8, device="cuda"),             # wrong shape
+                torch.empty((1, 64, 96, 3), dtype=torch.int8, device="cuda"),              # wrong type
+                torch.empty((1, 64, 96, 3), dtype=torch.uint8)):                           # wrong device
+        with pytest.raises(ValueError):
+            eng.forward_u8(img, out=bad)
+    with pytest.raises(ValueError):
+        eng.forward_f32(torch.rand(1, 3, 16, 24), out=torch.empty((1, 3, 64, 96), dtype=torch.float16, device="cuda"))

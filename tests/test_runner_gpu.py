@@ -181,3 +181,29 @@ def test_batch_driver_directory_and_stream(tmp_path):
             want = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
         assert np.array_equal(got, want), name
     assert batch.main([str(tmp_path / "missing.srmi"), str(src), str(dst)]) == -1
+
+
+def test_truncated_or_corrupt_weight_files_are_rejected(tmp_path):
+    """A short or damaged file makes <m>_init return -1 with a message; nothing is thrown across the C boundary."""
+    L = _lib.lib()
+    model, _ = H.build_model(dict(arch="rrdbnet", num_block=1, scale=4, seed=2, input="unit"), "f16")
+    path = str(tmp_path / "RealESRGAN_x4plus_ok.srmi")
+    export.save_weights(model, path)
+    data = open(path, "rb").read()
+    cases = {"half": data[:len(data) // 2], "header_only": data[:48], "empty": b"",
+             "bad_magic": b"NOTSRMI!" + data[8:]}
+    # a tensor whose header claims 2^31 elements (first tensor's first dim overwritten)
+    import struct
+    name_len = struct.unpack_from("<i", data, 48)[0]
+    dims_at = 48 + 4 + name_len + 4
+    huge = bytearray(data)
+    struct.pack_into("<q", huge, dims_at, 1 << 31)
+    cases["huge_dim"] = bytes(huge)
+    for tag, blob in cases.items():
+        p = str(tmp_path / f"RealESRGAN_x4plus_{tag}.srmi")
+        open(p, "wb").write(blob)
+        ctx = RealesrganCtx()
+        assert L.realesrgan_init(p.encode(), C.byref(ctx)) == -1, tag
+        assert ctx.initialized == 0
+        msg = L.srmi_last_error().decode()
+        assert ("truncated or corrupt" in msg) or ("not an SRMIW001" in msg), (tag, msg)
