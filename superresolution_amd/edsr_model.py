@@ -44,8 +44,10 @@ class ResBlock(nn.Module):
     """Parameter container: body.0 (conv, then ReLU) and body.2 (conv), indices as in the
     reference's nn.Sequential(conv, act, conv) (edsr_model.py:31-42)."""
 
-    def __init__(self, n_feats, res_scale=1.0):
+    def __init__(self, conv, n_feats, kernel_size, bias=True, bn=False, act=None, res_scale=1):
+        # the reference's signature (edsr_model.py:31); the engine implements what the reference networks use
         super().__init__()
+        _check_block_options(conv, kernel_size, bias, bn, act)
         self.body = nn.Sequential(conv_params(n_feats, n_feats, 3), nn.ReLU(True), conv_params(n_feats, n_feats, 3))
         self.res_scale = res_scale
 
@@ -54,7 +56,9 @@ class Upsampler(nn.Sequential):
     """conv C->4C + PixelShuffle(2) per factor of two, or conv C->9C + PixelShuffle(3)
     (edsr_model.py:50-77); conv indices 0, 2, ... as in the reference."""
 
-    def __init__(self, scale, n_feats):
+    def __init__(self, conv, scale, n_feats, bn=False, act=False, bias=True):
+        # the reference's signature (edsr_model.py:52)
+        _check_block_options(conv, 3, bias, bn, None if act in (False, None) else act)
         m = []
         if scale >= 2 and (scale & (scale - 1)) == 0:
             for _ in range(int(round(math.log2(scale)))):
@@ -64,6 +68,15 @@ class Upsampler(nn.Sequential):
         else:
             raise NotImplementedError(f"scale {scale} is not supported")
         super().__init__(*m)
+
+
+def _check_block_options(conv, kernel_size, bias, bn, act):
+    """Options of the reference's building blocks that its three networks never use have no kernel here."""
+    _check_conv(conv)
+    if kernel_size != 3 or not bias or bn:
+        raise NotImplementedError("the HIP engine implements 3x3 convolutions with bias and without batch norm")
+    if act is not None and not isinstance(act, nn.ReLU):
+        raise NotImplementedError("the HIP engine implements the ReLU blocks of the reference networks")
 
 
 def _check_conv(conv):
@@ -80,9 +93,10 @@ class _EDSRBase(HipModule):
             self.sub_mean = MeanShift(rgb_range)
             self.add_mean = MeanShift(rgb_range, sign=1)
         self.head = nn.Sequential(conv_params(3, n_feats, 3))
-        self.body = nn.Sequential(*[ResBlock(n_feats, res_scale) for _ in range(n_resblocks)],
+        self.body = nn.Sequential(*[ResBlock(default_conv, n_feats, 3, act=nn.ReLU(True), res_scale=res_scale)
+                                    for _ in range(n_resblocks)],
                                   conv_params(n_feats, n_feats, 3))
-        self.tail = nn.Sequential(Upsampler(scale, n_feats), conv_params(n_feats, 3, 3))
+        self.tail = nn.Sequential(Upsampler(default_conv, scale, n_feats, act=False), conv_params(n_feats, 3, 3))
 
     def _engine_config(self):
         return dict(arch=_lib.ARCH_EDSR, scale=self.scale, n_feats=self.n_feats, n_blocks=self.n_resblocks,

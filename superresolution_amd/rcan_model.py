@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import _lib
 from .edsr_model import MeanShift as _IdentityMeanShift
-from .edsr_model import Upsampler, default_conv  # noqa: F401  (same layers, rcan_model.py:17-58)
+from .edsr_model import Upsampler, _check_block_options, default_conv  # noqa: F401  (same layers, rcan_model.py:17-58)
 from .engine import HipModule, conv_params
 
 
@@ -40,8 +40,10 @@ class CALayer(nn.Module):
 class RCAB(nn.Module):
     """body.0 conv (+ReLU), body.2 conv, body.3 CALayer (rcan_model.py:81-92)."""
 
-    def __init__(self, n_feats, reduction, res_scale=1.0):
+    def __init__(self, conv, n_feats, kernel_size, reduction, bias=True, bn=False, act=None, res_scale=1):
+        # the reference's signature (rcan_model.py:81)
         super().__init__()
+        _check_block_options(conv, kernel_size, bias, bn, act)
         self.body = nn.Sequential(conv_params(n_feats, n_feats, 3), nn.ReLU(True), conv_params(n_feats, n_feats, 3),
                                   CALayer(n_feats, reduction))
         self.res_scale = res_scale
@@ -50,9 +52,12 @@ class RCAB(nn.Module):
 class ResidualGroup(nn.Module):
     """body.0..n-1 RCABs, body.n conv (rcan_model.py:102-107)."""
 
-    def __init__(self, n_feats, reduction, res_scale, n_resblocks):
+    def __init__(self, conv, n_feats, kernel_size, reduction, act, res_scale, n_resblocks):
+        # the reference's signature (rcan_model.py:102)
         super().__init__()
-        self.body = nn.Sequential(*[RCAB(n_feats, reduction, res_scale) for _ in range(n_resblocks)],
+        _check_block_options(conv, kernel_size, True, False, act)
+        self.body = nn.Sequential(*[RCAB(conv, n_feats, kernel_size, reduction, act=act, res_scale=res_scale)
+                                    for _ in range(n_resblocks)],
                                   conv_params(n_feats, n_feats, 3))
 
 
@@ -67,9 +72,9 @@ class _RCANBase(HipModule):
             self.sub_mean = MeanShift(rgb_range)
             self.add_mean = MeanShift(rgb_range, sign=1)
         self.head = nn.Sequential(conv_params(3, n_feats, 3))
-        self.body = nn.Sequential(*[ResidualGroup(n_feats, reduction, res_scale, n_resblocks)
+        self.body = nn.Sequential(*[ResidualGroup(default_conv, n_feats, 3, reduction, nn.ReLU(True), res_scale, n_resblocks)
                                     for _ in range(n_resgroups)], conv_params(n_feats, n_feats, 3))
-        self.tail = nn.Sequential(Upsampler(scale, n_feats), conv_params(n_feats, 3, 3))
+        self.tail = nn.Sequential(Upsampler(default_conv, scale, n_feats, act=False), conv_params(n_feats, 3, 3))
 
     def _engine_config(self):
         return dict(arch=_lib.ARCH_RCAN, scale=self.scale, n_feats=self.n_feats, n_blocks=self.n_resblocks,

@@ -52,6 +52,23 @@ def test_constructor_signatures_match_reference():
         realesrgan_model.RRDBNet(scale=3)
     with pytest.raises(NotImplementedError):
         edsr_model.EDSR(n_resblocks=1, n_feats=32, scale=5)
+    # building blocks: the reference's argument order (edsr_model.py:31,52; rcan_model.py:39,81,102)
+    assert names(edsr_model.ResBlock.__init__) == ["conv", "n_feats", "kernel_size", "bias", "bn", "act", "res_scale"]
+    assert names(edsr_model.Upsampler.__init__) == ["conv", "scale", "n_feats", "bn", "act", "bias"]
+    assert names(rcan_model.RCAB.__init__) == ["conv", "n_feats", "kernel_size", "reduction", "bias", "bn", "act", "res_scale"]
+    assert names(rcan_model.ResidualGroup.__init__) == ["conv", "n_feats", "kernel_size", "reduction", "act", "res_scale", "n_resblocks"]
+    conv, relu = edsr_model.default_conv, torch.nn.ReLU(True)
+    rb = edsr_model.ResBlock(conv, 32, 3, act=relu, res_scale=0.1)
+    assert list(rb.state_dict()) == ["body.0.weight", "body.0.bias", "body.2.weight", "body.2.bias"] and rb.res_scale == 0.1
+    assert list(edsr_model.Upsampler(conv, 4, 32, act=False).state_dict()) == ["0.weight", "0.bias", "2.weight", "2.bias"]
+    rg = rcan_model.ResidualGroup(conv, 32, 3, 16, relu, 1, 2)
+    assert "body.1.body.3.conv_du.2.bias" in rg.state_dict() and "body.2.weight" in rg.state_dict()
+    for bad in (lambda: edsr_model.ResBlock(conv, 32, 5), lambda: edsr_model.ResBlock(conv, 32, 3, bn=True),
+                lambda: edsr_model.ResBlock(conv, 32, 3, bias=False), lambda: edsr_model.Upsampler(conv, 2, 32, act="prelu"),
+                lambda: rcan_model.RCAB(conv, 32, 3, 16, act=torch.nn.PReLU()),
+                lambda: rcan_model.RCAB(torch.nn.Conv2d, 32, 3, 16)):
+        with pytest.raises(NotImplementedError):
+            bad()
 
 
 def test_filename_heuristics_match_reference(golden_dir):
