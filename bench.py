@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--plain-f16", action="store_true",
                     help="RRDBNet f16: keep 11 significant bits in the dense blocks' grown channels too "
                          "(default: 8 there, srmi_model_set_growth_round8)")
+    ap.add_argument("--no-fused-attention", action="store_true",
+                    help="RCAN: separate elementwise pass per channel-attention block instead of the gated conv input")
     ap.add_argument("--w8a8", action="store_true",
                     help="RRDBNet: calibrate on synthetic frames and run the dense blocks in int8 (a lower-precision "
                          "configuration of its own; never the headline)")
@@ -270,6 +272,8 @@ def main():
         models.append(model)
         engs.append(model.engine())
         engs[-1].set_sweep(args.sweep)
+        if args.no_fused_attention:
+            engs[-1].set_fused_attention(False)
         engs[-1].set_lanes(args.lanes)
         if args.w8a8:
             engs[-1].calibrate(np.stack([synth.smooth_image(h, w, 900 + i) for i in range(4)] +

@@ -133,6 +133,18 @@ typedef struct {
      * is multiplied by wscale[o] (= weight scale * input activation scale, packed order like `bias`) before the
      * bias is added; NULL for the float types. */
     const float* wscale;
+    /* Gated input (f16 / bf16 compute): with in_gate.ptr set the convolution reads
+     *   x' = in + gate_alpha * (in_gate * gate[n][c])        gate: float[n][cin] (device)
+     * instead of `in`, i.e. the output of a channel-attention block (RCAB.forward, rcan_model.py:94-97; `in` = the
+     * block's input, in_gate = its body before the attention scale, gate = srmi_ca_scale's result), so the block's
+     * last elementwise pass over the image is folded into the convolution that consumes it (the next block's
+     * first convolution, or the group's last one, rcan_model.py:104-112).  x' has the bits srmi_ca_apply would
+     * store; it is also written to in_sum (if in_sum.ptr; a tensor other than in / in_gate) for the next residual. */
+    srmi_tensor_t in_gate;
+    const float* gate;
+    float gate_alpha;
+    int32_t reserved;
+    srmi_tensor_t in_sum;
 } srmi_conv_desc_t;
 
 int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream);
@@ -300,6 +312,10 @@ size_t srmi_model_workspace_bytes(const srmi_model_t* m);
 /* Images a forward call sweeps through each layer together (default 1: one image per
  * layer sweep keeps its activations in the 256 MiB Infinity Cache). */
 int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep);
+/* RCAN with a half-precision trunk: 1 (default) lets the convolution that consumes a channel-attention block's
+ * output form it while loading (srmi_conv3x3's gated input) instead of a separate srmi_ca_apply pass over the
+ * image; 0 keeps the separate pass.  Both give the same bytes. */
+int srmi_model_set_fused_attention(srmi_model_t* m, int on);
 /* Internal HIP streams (1..4, default 3) over which the sweeps of one forward call are spread.
  * The lanes fork from and join the caller's stream through events, so a call is ordered on the
  * caller's stream exactly as with one lane; a call with a single sweep uses the caller's stream

@@ -45,7 +45,9 @@ class ConvDesc(C.Structure):
                 ("chansum", C.c_void_p), ("tail_out", C.c_void_p),
                 ("tail_mat", C.c_float * 9), ("tail_bias", C.c_float * 3),
                 ("tail_lo", C.c_float), ("tail_hi", C.c_float), ("tail_scale", C.c_float),
-                ("tail_round", C.c_int32), ("wscale", C.c_void_p)]
+                ("tail_round", C.c_int32), ("wscale", C.c_void_p),
+                ("in_gate", Tensor), ("gate", C.c_void_p), ("gate_alpha", C.c_float), ("reserved", C.c_int32),
+                ("in_sum", Tensor)]
 
 
 class ConvFirstDesc(C.Structure):
@@ -71,7 +73,7 @@ EXPORTS = [
     "srmi_resize_bilinear_u8",
     "srmi_model_create", "srmi_model_destroy", "srmi_model_set_tensor", "srmi_model_num_keys",
     "srmi_model_key", "srmi_model_finalize", "srmi_model_forward_f32", "srmi_model_forward_u8",
-    "srmi_model_workspace_bytes", "srmi_model_set_sweep", "srmi_model_set_lanes", "srmi_model_set_growth_round8", "srmi_model_flops", "srmi_model_set_rgb_shift",
+    "srmi_model_workspace_bytes", "srmi_model_set_sweep", "srmi_model_set_fused_attention", "srmi_model_set_lanes", "srmi_model_set_growth_round8", "srmi_model_flops", "srmi_model_set_rgb_shift",
     "srmi_absmax", "srmi_model_calibrate_begin", "srmi_model_calibrate_end", "srmi_model_set_w8a8",
     "srmi_model_calibration", "srmi_model_set_calibration", "srmi_model_reserve", "srmi_model_forward_u8_host", "srmi_model_reserve_host",
     "srmi_model_forward_u8_noalloc", "srmi_static_workspace_bytes",
@@ -148,6 +150,8 @@ def lib():
         L.srmi_model_workspace_bytes.argtypes = [C.c_void_p]
         L.srmi_model_workspace_bytes.restype = C.c_size_t
         L.srmi_model_set_sweep.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(L, "srmi_model_set_fused_attention"):
+            L.srmi_model_set_fused_attention.argtypes = [C.c_void_p, C.c_int]
         L.srmi_model_set_lanes.argtypes = [C.c_void_p, C.c_int]
         L.srmi_model_set_growth_round8.argtypes = [C.c_void_p, C.c_int]
         L.srmi_model_flops.argtypes = [C.c_void_p, C.c_int, C.c_int]

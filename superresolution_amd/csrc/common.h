@@ -70,6 +70,10 @@ struct ConvParams {
     const char* wpk;
     const float* bias;
     const float* wscale;  // SRMI_I8: per-output-channel dequantisation scale (packed order), else null
+    // gated input: the conv reads in + gate_alpha * (in_gate * gate[n][c]) and stores it to in_sum (if set)
+    TView in_gate, in_sum;
+    const float* gate;
+    float gate_alpha;
     float alpha, beta;
     TView res1, res2, out, out2;
     float* chansum;

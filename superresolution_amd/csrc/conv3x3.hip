@@ -101,6 +101,7 @@ struct ConvGeom {
     // an 8-row tile needs exactly 40 KiB and four workgroups share a CU's 160 KiB, a 12-row tile 48 KiB (three)
     static constexpr int LDS_TOTAL = LDS_BYTES;
     static constexpr int BIAS_OFFSET = 8192;               // behind the tile sums (kNW * 32 * NB floats <= 8 KiB)
+    static constexpr int GATE_BYTES = 1024;                // gated input: float[cin <= 256] behind the stage ring
     // waves per SIMD the register budget is held to: 4 for the 8-row tile (<= 128 registers), else 2
     static constexpr int MIN_WAVES = (MB == 2 && NB == 1 && kNW == 4) ? 4 : (kNW == 4 ? 2 : 4);
 };
@@ -454,7 +455,7 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
     }
 }
 
-template <int DT, int MB, int NB>
+template <int DT, int MB, int NB, bool GATE>
 __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     using G = ConvGeom<MB, NB>;
@@ -548,6 +549,87 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
         for (int q = 0; q < PPW; ++q) issue_piece(ra, rb, smem + buf * G::STAGE_BYTES, q);
     };
 
+    // ---- gated input (channel attention folded into the consumer) --------------------------------
+    // The convolution reads  in + gate_alpha * (in_gate * gate[n][c])  instead of `in`: the pixel pieces of a
+    // stage are fetched into registers (same per-lane offsets, out-of-image lanes read zeros from both
+    // tensors), combined with the arithmetic of ca_apply_kernel and written to the stage slot with
+    // ds_write; interior pixels of the tile are also stored to `in_sum`, the trunk the next block adds to.
+    static_assert(!GATE || (G::NS == 2 && (DT == SRMI_F16 || DT == SRMI_BF16)), "gated input: half types, two-slot ring");
+    u32x4 gx[GATE ? APW : 1], gt[GATE ? APW : 1];
+    unsigned keep = 0;  // bit j: piece j of this lane is an in-image pixel of the tile's interior
+    const float* gate_lds = (const float*)(smem + G::LDS_BYTES);
+    const char* gate_img = nullptr;
+    char* sum_img = nullptr;
+    if constexpr (GATE) {
+        gate_img = p.in_gate.ptr + (long long)n * p.in_gate.img_stride_b;
+        sum_img = p.in_sum.ptr ? p.in_sum.ptr + (long long)n * p.in_sum.img_stride_b : nullptr;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int i = (wave + kNW * j) * 64 + lane;
+            const int pp = i >> 1;
+            const int rho = pp / PW, xi = pp - rho * PW;
+            const bool interior = rho >= 1 && rho <= TH && xi >= 1 && xi <= kTileW;
+            if (interior && aoff[j] != SRMI_OOB_OFFSET) keep |= 1u << j;
+        }
+    }
+    auto gate_fetch = [&](const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rt, const int q) {
+        if constexpr (GATE) {
+            if (wave + kNW * q < G::A_PIECES) {
+                gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], 0, 0));
+                gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, aoff[q], 0, 0));
+            }
+        }
+    };
+    auto gate_rsrc = [&](int s) { return make_rsrc(gate_img + (long long)s * p.in_gate.plane_stride_b, plane_bytes); };
+    auto gate_commit = [&](const int s, char* abuf) {
+        if constexpr (GATE) {
+            const auto rx = make_rsrc(sum_img + (long long)s * p.in_sum.plane_stride_b, sum_img ? plane_bytes : 0u);
+#pragma unroll
+            for (int q = 0; q < APW; ++q) {
+                const int k = wave + kNW * q;
+                if (k < G::A_PIECES) {
+                    const int i = k * 64 + lane;
+                    const int c = (i & 1) ^ ((i >> 4) & 1);  // logical chunk of this lane's LDS chunk
+                    const float* g = gate_lds + s * 16 + c * 8;
+                    const f32x4 g0 = *(const f32x4*)g, g1 = *(const f32x4*)(g + 4);
+                    float xv[8], tv[8];
+                    if constexpr (DT == SRMI_F16) {
+                        const f16x8 xh = __builtin_bit_cast(f16x8, gx[q]), th = __builtin_bit_cast(f16x8, gt[q]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { xv[j] = (float)xh[j]; tv[j] = (float)th[j]; }
+                    } else {
+                        const bf16x8 xh = __builtin_bit_cast(bf16x8, gx[q]), th = __builtin_bit_cast(bf16x8, gt[q]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { xv[j] = (float)xh[j]; tv[j] = (float)th[j]; }
+                    }
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (tv[j] * g0[j]) * p.gate_alpha + xv[j];
+                        o[4 + j] = (tv[4 + j] * g1[j]) * p.gate_alpha + xv[4 + j];
+                    }
+                    u32x4 v;
+                    if constexpr (DT == SRMI_F16) {
+                        f16x8 oh;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) oh[j] = to_f16_sat(o[j]);
+                        v = __builtin_bit_cast(u32x4, oh);
+                    } else {
+                        bf16x8 oh;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) oh[j] = (__bf16)o[j];
+                        v = __builtin_bit_cast(u32x4, oh);
+                    }
+                    *(u32x4*)(abuf + k * 1024 + lane * 16) = v;
+                    if (sum_img)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rx, ((keep >> q) & 1u) ? aoff[q] : SRMI_OOB_OFFSET, 0, 0);
+                }
+            }
+            // the stage's barrier must find these writes in LDS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+
     f32x16 acc[MB][NB];
 #pragma unroll
     for (int r = 0; r < MB; ++r)
@@ -600,7 +682,21 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
     const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     STAMP();
-    issue(0, 0);
+    if constexpr (GATE) {
+        if (tid < p.ncb * 16) ((float*)(smem + G::LDS_BYTES))[tid] = p.gate[(long long)n * p.ncb * 16 + tid];
+        const auto ra = pixel_rsrc(0);
+        const auto rt = gate_rsrc(0);
+        const auto rb = weight_rsrc(0);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            if (q < APW) gate_fetch(ra, rt, q);
+            else issue_piece(ra, rb, smem, q);
+        }
+        __syncthreads();  // the gate vector is in LDS
+        gate_commit(0, smem);
+    } else {
+        issue(0, 0);
+    }
     // this thread's bias value waits in a register until the stage buffers are free
     const float bias_v = tid < 32 * NB ? p.bias[ct * 32 * NB + tid] : 0.f;
     float scale_v = 0.f;
@@ -661,7 +757,7 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
     // the 8-12-stage layers of a dense block, but -4 % on 4-stage layers, which keep the second).
     constexpr int kCarriedMinStages = 8;
     bool carried = false;
-    if constexpr (G::NS == 2) carried = nstage >= kCarriedMinStages;
+    if constexpr (G::NS == 2 && !GATE) carried = nstage >= kCarriedMinStages;
     if (carried) {
     // Fragment-carried pipeline (two-slot ring).  The barrier of a stage sits after the LAST LDS read
     // of the stage has returned, not after its last MFMA: the final third of the stage's MFMAs only
@@ -747,6 +843,7 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
         const int sn = more ? s + ahead : s;
         const auto ra = pixel_rsrc(sn);
         const auto rb = weight_rsrc(sn);
+        const auto rt = gate_rsrc(GATE ? sn : 0);
         char* nbuf = smem + slot * G::STAGE_BYTES;
 #ifdef SRMI_BULK_ISSUE  // diagnostic build: the whole next stage is issued before the multiply steps
         if (more) issue(sn, slot);
@@ -755,7 +852,10 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
 #ifndef SRMI_BULK_ISSUE
             if (i % GAP == GAP - 1 && i / GAP < PPW) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_piece(ra, rb, nbuf, i / GAP);
+                if (more) {
+                    if (GATE && i / GAP < APW) gate_fetch(ra, rt, i / GAP < APW ? i / GAP : 0);
+                    else issue_piece(ra, rb, nbuf, i / GAP);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
@@ -797,6 +897,9 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
         mma_frag(f0, 1, after);
         __builtin_amdgcn_sched_barrier(0);
 #endif
+        if constexpr (GATE) {
+            if (more) gate_commit(sn, nbuf);
+        }
         STAMP();
         cur = cur + 1 == G::NS ? 0 : cur + 1;
     }
@@ -871,26 +974,26 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
 // ---- host launcher --------------------------------------------------------------------------------
 // The dynamic-LDS limit is a per-device attribute of the function: set once on every device used.  Setting
 // it twice is harmless, so concurrent first calls only need the bookkeeping itself to be atomic.
-template <int DT, int MB, int NB>
+template <int DT, int MB, int NB, bool GATE>
 static int configure() {
     static std::atomic<unsigned long long> configured{0};
     int dev = 0;
     SRMI_HIP(hipGetDevice(&dev));
     const bool tracked = dev >= 0 && dev < 64;
     if (!tracked || !(configured.load(std::memory_order_acquire) >> dev & 1ull)) {
-        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvGeom<MB, NB>::LDS_TOTAL));
+        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB, GATE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0)));
         if (tracked) configured.fetch_or(1ull << dev, std::memory_order_release);
     }
     return 0;
 }
 
-template <int DT, int MB, int NB>
+template <int DT, int MB, int NB, bool GATE = false>
 static int launch(const ConvParams& p, hipStream_t stream) {
-    constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL;
-    if (configure<DT, MB, NB>()) return -1;
+    constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0);
+    if (configure<DT, MB, NB, GATE>()) return -1;
     dim3 grid(p.tiles_x * p.tiles_y, p.cout / (32 * NB), p.n);
-    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB>), grid, dim3(64 * kNW), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB, GATE>), grid, dim3(64 * kNW), lds, stream, p);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
@@ -900,6 +1003,12 @@ static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
     if constexpr (DT == SRMI_I8) {  // dense-block shapes only: 32-wide output tiles, 8- or 12-row tiles
         if (nb != 1 || mb == 4) SRMI_FAIL("srmi_conv3x3: int8 needs cout_tile 32 and rows_per_wave 2 or 3");
         return mb == 2 ? launch<DT, 2, 1>(p, s) : launch<DT, 3, 1>(p, s);
+    }
+    if constexpr (DT == SRMI_F16 || DT == SRMI_BF16) {
+        if (p.in_gate.ptr) {  // validated by the caller: rows_per_wave 2 or 3
+            if (nb == 1) return mb == 2 ? launch<DT, 2, 1, true>(p, s) : launch<DT, 3, 1, true>(p, s);
+            return mb == 2 ? launch<DT, 2, 2, true>(p, s) : launch<DT, 3, 2, true>(p, s);
+        }
     }
     if (nb == 1) {
         if (mb == 2) return launch<DT, 2, 1>(p, s);
@@ -913,9 +1022,13 @@ static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
 
 template <int DT>
 static int configure_dt() {
-    if constexpr (DT == SRMI_I8) return configure<DT, 2, 1>() || configure<DT, 3, 1>();
-    return configure<DT, 2, 1>() || configure<DT, 3, 1>() || configure<DT, 4, 1>() || configure<DT, 2, 2>() ||
-           configure<DT, 3, 2>();
+    if constexpr (DT == SRMI_I8) return configure<DT, 2, 1, false>() || configure<DT, 3, 1, false>();
+    if constexpr (DT == SRMI_F16 || DT == SRMI_BF16) {
+        if (configure<DT, 2, 1, true>() || configure<DT, 3, 1, true>() || configure<DT, 2, 2, true>() || configure<DT, 3, 2, true>())
+            return -1;
+    }
+    return configure<DT, 2, 1, false>() || configure<DT, 3, 1, false>() || configure<DT, 4, 1, false>() ||
+           configure<DT, 2, 2, false>() || configure<DT, 3, 2, false>();
 }
 
 static int default_rows_per_wave() { return 3; }  // 12-row tiles: the fastest variant on every layer measured
@@ -969,6 +1082,15 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     if (r > 1 && (d->cout % (r * r * 32) || d->out2.ptr || d->res1.ptr || d->res2.ptr))
         SRMI_FAIL("srmi_conv3x3: pixel-shuffle store needs cout %% (32*r*r) == 0 and no residual/out2");
     if (d->in_up2 && ((d->h | d->w) & 1)) SRMI_FAIL("srmi_conv3x3: in_up2 needs even h and w");
+    if (d->in_gate.ptr) {
+        if (d->dtype != SRMI_F16 && d->dtype != SRMI_BF16) SRMI_FAIL("srmi_conv3x3: a gated input needs f16 or bf16 compute");
+        if (d->in_gate.dtype != d->dtype || !d->gate) SRMI_FAIL("srmi_conv3x3: in_gate must be of the compute dtype and come with a gate vector");
+        if (d->in_up2 || d->cin > 256 || mb > 3) SRMI_FAIL("srmi_conv3x3: a gated input excludes in_up2, cin > 256 and rows_per_wave 4");
+        if (d->in_sum.ptr && (d->in_sum.dtype != d->dtype || d->in_sum.ptr == d->in.ptr || d->in_sum.ptr == d->in_gate.ptr))
+            SRMI_FAIL("srmi_conv3x3: in_sum must be a separate tensor of the compute dtype");
+    } else if (d->in_sum.ptr || d->gate) {
+        SRMI_FAIL("srmi_conv3x3: in_sum / gate without in_gate");
+    }
     if ((long long)d->h * d->w * kPixBytes * r * r >= (1ll << 32)) SRMI_FAIL("srmi_conv3x3: plane larger than 4 GiB");
 
     ConvParams p;
@@ -990,6 +1112,8 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     }
     p.wpk = (const char*)d->wpk; p.bias = d->bias;
     p.wscale = d->wscale;
+    p.in_gate = to_view(d->in_gate); p.in_sum = to_view(d->in_sum);
+    p.gate = d->gate; p.gate_alpha = d->gate_alpha;
     p.alpha = d->alpha; p.beta = d->beta;
     p.res1 = to_view(d->res1); p.res2 = to_view(d->res2);
     p.out = to_view(d->out); p.out2 = to_view(d->out2);

@@ -89,6 +89,7 @@ struct srmi_model {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     int sweep = 1;
+    bool fuse_attention = true;  // RCAN, half-precision trunk: attention output formed by the consuming conv
     int mb_override = 0;
     // RRDBNet, f16: the grown channels x1..x4 of every dense block (and the weights that multiply them)
     // carry 8 significant bits; the trunk keeps full f16 precision (see srmi_model_set_growth_round8)
@@ -336,14 +337,34 @@ static int pick_rows_per_wave(const srmi_model* m, int h) {
     return h <= 8 ? 2 : 3;
 }
 
+// Rows per wave of a convolution with a gated input: its pixel pieces pass through registers, which the 12-row
+// variant of the 64-channel tile does not have to spare.
+static int gate_rows_per_wave(const srmi_model* m, int h) {
+    if (m->mb_override) return m->mb_override > 3 ? 3 : m->mb_override;
+#ifdef SRMI_DIAG
+    if (getenv("SRMI_GATE_MB")) return atoi(getenv("SRMI_GATE_MB"));
+#endif
+    (void)h;
+    return 2;
+}
+
 struct Exec {
     srmi_model* m;
     hipStream_t stream;
     int ns;  // images in this sweep
 
+    // input of a conv that consumes a channel-attention block's output without materialising it first
+    struct Gate {
+        srmi_tensor_t body;   // the block's body before the attention scale
+        const float* scale;   // float[ns][c]
+        float alpha;          // res_scale
+        srmi_tensor_t sum;    // where the block's output is stored on the way (ptr NULL: nowhere)
+    };
+
     int conv(const std::string& name, const srmi_tensor_t& in, int h, int w, int act, bool up2,
              float alpha, const srmi_tensor_t* res1, float beta, const srmi_tensor_t* res2,
-             const srmi_tensor_t* out, const srmi_tensor_t* out2, float* chansum = nullptr, int force_mb = 0) {
+             const srmi_tensor_t* out, const srmi_tensor_t* out2, float* chansum = nullptr, int force_mb = 0,
+             const Gate* gate = nullptr) {
         auto it = m->convs.find(name);
         if (it == m->convs.end()) SRMI_FAIL("internal: conv '%s' not uploaded", name.c_str());
         const ConvW& cw = it->second;
@@ -362,6 +383,9 @@ struct Exec {
         if (out) d.out = *out;
         if (out2) d.out2 = *out2;
         d.chansum = chansum;
+        if (gate) {
+            d.in_gate = gate->body; d.gate = gate->scale; d.gate_alpha = gate->alpha; d.in_sum = gate->sum;
+        }
         return srmi_conv3x3(&d, stream);
     }
 
@@ -741,17 +765,34 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
         int kr = 0;   // XR[kr] holds it in the trunk dtype (split mode), when trunk_in_xr
         bool trunk_in_xr = false;
         int ca_index = 0;
+        // Half-precision trunk: a block's output x + res_scale * (y * s) is never written by a pass of its own;
+        // the convolution that consumes it (the next block's first, or the group's last) forms it while
+        // loading and, where a later residual needs it, stores it on the way.
+        const bool fused = m->fuse_attention && !split && (T == SRMI_F16 || T == SRMI_BF16) && nf <= 256;
         for (int g = 0; g < d.n_groups; ++g) {
             const Buf& Gin = g == 0 ? H : GI[g & 1];
+            bool pending = false;  // XT[k] + res_scale * (Y * scale) is the trunk, not yet stored
             for (int b = 0; b < d.n_blocks; ++b) {
                 snprintf(name, sizeof(name), "body.%d.body.%d.body.0", g, b);
                 const srmi_tensor_t in = tv(XT[k]), t = tv(Tm), y = tv(Y);
-                if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr)) return -1;
+                if (pending) {
+                    const Exec::Gate gate{y, scale, d.res_scale, tv(XT[k ^ 1])};
+                    if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr, nullptr,
+                                 gate_rows_per_wave(m, h), &gate)) return -1;
+                    k ^= 1;
+                    pending = false;
+                } else {
+                    if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr)) return -1;
+                }
                 snprintf(name, sizeof(name), "body.%d.body.%d.body.2", g, b);
                 const int mb = pick_rows_per_wave(m, h);
                 if (ex->conv(name, t, h, w, SRMI_ACT_NONE, false, 1.f, nullptr, 1.f, nullptr, &y, nullptr, chansum, mb)) return -1;
                 const CaW& ca = m->cas[ca_index++];
                 if (srmi_ca_scale(chansum, ns, srmi_conv3x3_tiles(h, w, mb), nf, cr, h * w, ca.w1, ca.b1, ca.w2, ca.b2, scale, ex->stream)) return -1;
+                if (fused) {
+                    pending = true;
+                    continue;
+                }
                 // x + res_scale * (y * s)   (rcan_model.py:94-97)
                 srmi_tensor_t xres;
                 if (!split) xres = tv(XT[k]);
@@ -765,7 +806,13 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
             // group tail conv + group input (rcan_model.py:109-112); its output is the next group's input
             snprintf(name, sizeof(name), "body.%d.body.%d", g, d.n_blocks);
             const srmi_tensor_t in = tv(XT[k]), res = tv(Gin), o1 = tv(XT[k ^ 1]), og = tv(GI[(g + 1) & 1]);
-            if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, &og)) return -1;
+            if (pending) {
+                const Exec::Gate gate{tv(Y), scale, d.res_scale, srmi_tensor_t{}};
+                if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, &og, nullptr,
+                             gate_rows_per_wave(m, h), &gate)) return -1;
+            } else {
+                if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, &og)) return -1;
+            }
             k ^= 1;
             trunk_in_xr = false;  // the trunk in trunk dtype is now GI[(g+1)&1]
         }
@@ -1299,6 +1346,12 @@ extern "C" int srmi_model_set_rgb_shift(srmi_model_t* m, const float* shift) {
 }
 
 extern "C" size_t srmi_model_workspace_bytes(const srmi_model_t* m) { return m ? m->ws_bytes : 0; }
+
+extern "C" int srmi_model_set_fused_attention(srmi_model_t* m, int on) {
+    if (!m) SRMI_FAIL("srmi_model_set_fused_attention: null model");
+    m->fuse_attention = on != 0;
+    return 0;
+}
 
 extern "C" int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep) {
     if (!m || images_per_sweep < 1) SRMI_FAIL("srmi_model_set_sweep: bad argument");

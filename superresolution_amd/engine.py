@@ -77,6 +77,11 @@ class Engine:
         check(lib().srmi_model_finalize(self._h), "srmi_model_finalize")
         self._finalized = True
 
+    def set_fused_attention(self, on):
+        """RCAN, half-precision trunk: whether the consuming convolution forms a channel-attention block's output
+        while loading (default) or a separate elementwise pass does; the results are the same bytes."""
+        check(lib().srmi_model_set_fused_attention(self._h, int(bool(on))), "srmi_model_set_fused_attention")
+
     def set_sweep(self, images_per_sweep):
         check(lib().srmi_model_set_sweep(self._h, int(images_per_sweep)), "srmi_model_set_sweep")
 

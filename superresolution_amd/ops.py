@@ -106,8 +106,12 @@ class PackedConv:
 
 def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Planes = None,
             beta=1.0, res2: Planes = None, out: Planes = None, out_c0=0, out_dtype=None,
-            out2: Planes = None, chansum=False, rows_per_wave=0, tail=None, out_round8=False, out_qscale=0.0):
+            out2: Planes = None, chansum=False, rows_per_wave=0, tail=None, out_round8=False, out_qscale=0.0,
+            in_gate: Planes = None, gate: torch.Tensor = None, gate_alpha=1.0, in_sum: Planes = None):
     """act(conv(x)+b)*alpha+res1 (*beta+res2) -> out (see srmi_conv3x3 in include/srmi355.h).
+
+    in_gate / gate / gate_alpha: the conv reads x + gate_alpha * (in_gate * gate[n][c]) (gate: f32 [n][cin] on the
+    GPU) and stores that sum to in_sum (if given).
 
     tail: None, or dict(mode=TAIL_*, mat=3x3, bias=3, lo, hi, scale, round) for the RGB layer.
     Returns out (Planes), or the tail tensor; with chansum=True returns (out, sums[n][tiles][c]).
@@ -124,7 +128,10 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
     d.alpha, d.beta = alpha, beta
     d.res1 = res1.view() if res1 is not None else _NULL
     d.res2 = res2.view() if res2 is not None else _NULL
-    keep = [x, pc, res1, res2]
+    keep = [x, pc, res1, res2, in_gate, gate, in_sum]
+    if in_gate is not None:
+        d.in_gate, d.gate, d.gate_alpha = in_gate.view(), gate.data_ptr(), gate_alpha
+        d.in_sum = in_sum.view() if in_sum is not None else _NULL
     sums = None
     result = None
     if tail is None:

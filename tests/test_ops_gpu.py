@@ -287,3 +287,33 @@ def test_conv_output_rounded_to_8_significant_bits():
     assert torch.equal(got, want)
     assert torch.equal(got, got.to(torch.bfloat16).to(torch.float32))
     assert not torch.equal(got, plain)
+
+
+@pytest.mark.parametrize("dt,name", [(_lib.F16, "f16"), (_lib.BF16, "bf16")])
+@pytest.mark.parametrize("mb", [2, 3])
+@pytest.mark.parametrize("c,cout", [(64, 64), (96, 32), (16, 64)])
+def test_gated_input_equals_ca_apply_then_conv(dt, name, mb, c, cout):
+    """A convolution reading x + alpha * (t * gate[c]) itself (RCAB output consumed by the next conv,
+    rcan_model.py:94-97) gives the bytes of ca_apply followed by the plain convolution, and stores the same sum."""
+    n, h, w = 2, 29, 71   # ragged tiles in both directions
+    x = q(rnd("x", (n, c, h, w), 1), dt)
+    t = q(rnd("t", (n, c, h, w), 2, 3.0), dt)
+    gate = (rnd("g", (n, c), 3) * 0.5 + 0.5).cuda().contiguous()
+    wt = q(rnd("w", (cout, c, 3, 3), 4, 0.1), dt)
+    b = rnd("b", (cout,), 5)
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt)
+    xp, tp = ops.Planes.from_nchw(x, dt), ops.Planes.from_nchw(t, dt)
+    summed = ops.ca_apply(tp, xp, gate, 0.7)
+    ref = ops.conv3x3(summed, pc, act=_lib.ACT_RELU, rows_per_wave=mb).to_nchw().cpu()
+    in_sum = ops.Planes(n, c, h, w, dt, zero=True)
+    got = ops.conv3x3(xp, pc, act=_lib.ACT_RELU, rows_per_wave=mb, in_gate=tp, gate=gate, gate_alpha=0.7, in_sum=in_sum)
+    torch.cuda.synchronize()
+    assert torch.equal(in_sum.to_nchw().cpu(), summed.to_nchw().cpu()), f"{name}: stored sum differs"
+    assert torch.equal(got.to_nchw().cpu(), ref), f"{name}: gated conv differs from ca_apply + conv"
+    # without the side store, and against the fp32 functional reference
+    got2 = ops.conv3x3(xp, pc, act=_lib.ACT_RELU, rows_per_wave=mb, in_gate=tp, gate=gate, gate_alpha=0.7)
+    assert torch.equal(got2.to_nchw().cpu(), ref)
+    xs = q(x + 0.7 * (t * gate.cpu()[:, :, None, None]), dt)
+    assert_close(ref, F.relu(F.conv2d(xs, wt, b, padding=1)), 2.0 ** -10 if dt == _lib.F16 else 2.0 ** -7, f"gated {name}")
+    with pytest.raises(_lib.SrmiError):
+        ops.conv3x3(xp, pc, in_gate=tp, gate=gate, in_sum=xp)   # the sum may not overwrite an input
