@@ -101,7 +101,8 @@ struct ConvGeom {
     // an 8-row tile needs exactly 40 KiB and four workgroups share a CU's 160 KiB, a 12-row tile 48 KiB (three)
     static constexpr int LDS_TOTAL = LDS_BYTES;
     static constexpr int BIAS_OFFSET = 8192;               // behind the tile sums (kNW * 32 * NB floats <= 8 KiB)
-    static constexpr int GATE_BYTES = 1024;                // gated input: float[cin <= 256] behind the stage ring
+    static constexpr int GATE_BYTES = 2048;                // gated input: float[cin <= 256] behind the stage ring, then
+                                                           // 1 KiB that absorbs the writes of pieces a wave does not own
     // waves per SIMD the register budget is held to: 4 for the 8-row tile (<= 128 registers), else 2
     static constexpr int MIN_WAVES = (MB == 2 && NB == 1 && kNW == 4) ? 4 : (kNW == 4 ? 2 : 4);
 };
@@ -456,7 +457,7 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 }
 
 template <int DT, int MB, int NB, bool GATE>
-__global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     using G = ConvGeom<MB, NB>;
     constexpr int TH = G::TH, PW = G::PW;
@@ -572,63 +573,73 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
             if (interior && aoff[j] != SRMI_OOB_OFFSET) keep |= 1u << j;
         }
     }
-    auto gate_fetch = [&](const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rt, const int q) {
-        if constexpr (GATE) {
-            if (wave + kNW * q < G::A_PIECES) {
-                gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], 0, 0));
-                gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, aoff[q], 0, 0));
-            }
-        }
-    };
     auto gate_rsrc = [&](int s) { return make_rsrc(gate_img + (long long)s * p.in_gate.plane_stride_b, plane_bytes); };
-    auto gate_commit = [&](const int s, char* abuf) {
+    auto sum_rsrc = [&](int s) {
+        return make_rsrc(sum_img + (long long)s * p.in_sum.plane_stride_b, sum_img ? plane_bytes : 0u);
+    };
+    // One STEP combines one channel of one piece (8 steps per piece, 8 * APW per stage).  The main loop runs
+    // the steps of stage s+1 between the MFMAs of stage s, so the conversions hide under the matrix pipe;
+    // the last step of a piece writes its 16 bytes to the stage slot (and to in_sum) and then requests the same
+    // piece of stage s+2, which so has a whole stage to arrive.
+    constexpr int kGateSteps = 8 * APW;
+    const float gate_alpha = p.gate_alpha;
+    f32x4 gg0 = {0.f, 0.f, 0.f, 0.f}, gg1 = {0.f, 0.f, 0.f, 0.f};
+    u32x4 gpk = {0u, 0u, 0u, 0u};
+    float gprev = 0.f;
+    // The steps contain no branch: between the request of a piece and its use the compiler must be able to COUNT
+    // the vector-memory operations issued (a conditional one in between makes it wait for all of them, the
+    // weight pieces just requested included).  What must not happen is masked instead: a piece this wave does
+    // not own reads with out-of-range offsets and writes to the spare KiB, a stage that does not exist is
+    // requested with out-of-range offsets (zeros, no traffic) and stored with them (dropped).
+    auto gate_step = [&](const int step, const int s, char* abuf, const __amdgpu_buffer_rsrc_t rx, const bool live,
+                         const bool fetch_next, const __amdgpu_buffer_rsrc_t ra_next, const __amdgpu_buffer_rsrc_t rt_next) {
         if constexpr (GATE) {
-            const auto rx = make_rsrc(sum_img + (long long)s * p.in_sum.plane_stride_b, sum_img ? plane_bytes : 0u);
-#pragma unroll
-            for (int q = 0; q < APW; ++q) {
-                const int k = wave + kNW * q;
-                if (k < G::A_PIECES) {
-                    const int i = k * 64 + lane;
-                    const int c = (i & 1) ^ ((i >> 4) & 1);  // logical chunk of this lane's LDS chunk
-                    const float* g = gate_lds + s * 16 + c * 8;
-                    const f32x4 g0 = *(const f32x4*)g, g1 = *(const f32x4*)(g + 4);
-                    float xv[8], tv[8];
-                    if constexpr (DT == SRMI_F16) {
-                        const f16x8 xh = __builtin_bit_cast(f16x8, gx[q]), th = __builtin_bit_cast(f16x8, gt[q]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { xv[j] = (float)xh[j]; tv[j] = (float)th[j]; }
-                    } else {
-                        const bf16x8 xh = __builtin_bit_cast(bf16x8, gx[q]), th = __builtin_bit_cast(bf16x8, gt[q]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { xv[j] = (float)xh[j]; tv[j] = (float)th[j]; }
-                    }
-                    float o[8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = (tv[j] * g0[j]) * p.gate_alpha + xv[j];
-                        o[4 + j] = (tv[4 + j] * g1[j]) * p.gate_alpha + xv[4 + j];
-                    }
-                    u32x4 v;
-                    if constexpr (DT == SRMI_F16) {
-                        f16x8 oh;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) oh[j] = to_f16_sat(o[j]);
-                        v = __builtin_bit_cast(u32x4, oh);
-                    } else {
-                        bf16x8 oh;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) oh[j] = (__bf16)o[j];
-                        v = __builtin_bit_cast(u32x4, oh);
-                    }
-                    *(u32x4*)(abuf + k * 1024 + lane * 16) = v;
-                    if (sum_img)
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rx, ((keep >> q) & 1u) ? aoff[q] : SRMI_OOB_OFFSET, 0, 0);
-                }
+            const int q = step >> 3, j = step & 7;
+            const int k = wave + kNW * q;
+            const bool mine = k < G::A_PIECES;
+            if (j == 0) {
+                const int i = k * 64 + lane;
+                const int c = (i & 1) ^ ((i >> 4) & 1);  // logical chunk of this lane's LDS chunk
+                const float* g = gate_lds + s * 16 + c * 8;
+                gg0 = *(const f32x4*)g;
+                gg1 = *(const f32x4*)(g + 4);
             }
-            // the stage's barrier must find these writes in LDS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float xv, tv;
+            if constexpr (DT == SRMI_F16) {
+                xv = (float)__builtin_bit_cast(f16x8, gx[q])[j];
+                tv = (float)__builtin_bit_cast(f16x8, gt[q])[j];
+            } else {
+                xv = (float)__builtin_bit_cast(bf16x8, gx[q])[j];
+                tv = (float)__builtin_bit_cast(bf16x8, gt[q])[j];
+            }
+            const float o = (tv * (j < 4 ? gg0[j & 3] : gg1[j & 3])) * gate_alpha + xv;
+            if (j & 1) {
+                if constexpr (DT == SRMI_F16) {
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    const f16x2 h = {to_f16_sat(gprev), to_f16_sat(o)};
+                    gpk[j >> 1] = __builtin_bit_cast(unsigned, h);
+                } else {
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    const bf16x2 h = {(__bf16)gprev, (__bf16)o};
+                    gpk[j >> 1] = __builtin_bit_cast(unsigned, h);
+                }
+            } else {
+                gprev = o;
+            }
+            if (j == 7) {
+                char* dst = mine ? abuf + k * 1024 : smem + G::LDS_BYTES + 1024;
+                *(u32x4*)(dst + lane * 16) = gpk;
+                __builtin_amdgcn_raw_buffer_store_b128(gpk, rx, (live && ((keep >> q) & 1u)) ? aoff[q] : SRMI_OOB_OFFSET, 0, 0);
+                const unsigned off = fetch_next ? aoff[q] : SRMI_OOB_OFFSET;
+                gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_next, off, 0, 0));
+                gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt_next, off, 0, 0));
+            }
         }
     };
+    // vector-memory operations of this wave that are younger than the weight pieces of a stage when that stage
+    // starts: per pixel piece one in_sum store and the two loads of the next fetch
+    constexpr int kGateYounger = 3 * APW;
+    static_assert(!GATE || kGateYounger <= 12, "a gated input supports at most four pixel pieces per wave");
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -684,16 +695,27 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
     STAMP();
     if constexpr (GATE) {
         if (tid < p.ncb * 16) ((float*)(smem + G::LDS_BYTES))[tid] = p.gate[(long long)n * p.ncb * 16 + tid];
-        const auto ra = pixel_rsrc(0);
-        const auto rt = gate_rsrc(0);
-        const auto rb = weight_rsrc(0);
+        {
+            const auto ra = pixel_rsrc(0);
+            const auto rt = gate_rsrc(0);
+            const auto rb = weight_rsrc(0);
 #pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-            if (q < APW) gate_fetch(ra, rt, q);
-            else issue_piece(ra, rb, smem, q);
+            for (int q = APW; q < PPW; ++q) issue_piece(ra, rb, smem, q);
+#pragma unroll
+            for (int q = 0; q < APW; ++q) {
+                gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], 0, 0));
+                gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, aoff[q], 0, 0));
+            }
         }
         __syncthreads();  // the gate vector is in LDS
-        gate_commit(0, smem);
+        {
+            const int s1 = nstage > 1 ? 1 : 0;
+            const auto rx = sum_rsrc(0);
+            const auto ra = pixel_rsrc(s1);
+            const auto rt = gate_rsrc(s1);
+#pragma unroll
+            for (int st = 0; st < kGateSteps; ++st) gate_step(st, 0, smem, rx, true, nstage > 1, ra, rt);
+        }
     } else {
         issue(0, 0);
     }
@@ -829,7 +851,11 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
     int cur = 0;  // ring slot of stage s
     for (int s = 0; s < nstage; ++s) {
         // stage s has landed once at most the younger stage's pieces are still outstanding
-        if (G::NS == 3 && s + 1 < nstage) wait_vmcnt_le(my_pieces);
+        if constexpr (GATE) {
+            // the weight pieces of stage s have landed once only the younger operations are outstanding; this
+            // wave's writes of the stage's pixels must be in LDS before the barrier
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kGateYounger) : "memory");
+        } else if (G::NS == 3 && s + 1 < nstage) wait_vmcnt_le(my_pieces);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // one barrier per stage: everybody's share of stage s is in LDS, and everybody is done
         // reading the slot that the next issue overwrites
@@ -843,19 +869,45 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
         const int sn = more ? s + ahead : s;
         const auto ra = pixel_rsrc(sn);
         const auto rb = weight_rsrc(sn);
-        const auto rt = gate_rsrc(GATE ? sn : 0);
+        // gated input: the steps below build stage s+1 and request stage s+2
+        const bool more2 = s + 2 < nstage;
+        const int sn2 = more2 ? s + 2 : s;
+        const auto rx = sum_rsrc(GATE ? sn : 0);
+        const auto ra2 = pixel_rsrc(GATE ? sn2 : 0);
+        const auto rt2 = gate_rsrc(GATE ? sn2 : 0);
         char* nbuf = smem + slot * G::STAGE_BYTES;
 #ifdef SRMI_BULK_ISSUE  // diagnostic build: the whole next stage is issued before the multiply steps
         if (more) issue(sn, slot);
 #endif
         auto after = [&](const int i) {
+            if constexpr (GATE) {
+                // weight pieces first (the counted wait above relies on everything after them being younger),
+                // then the steps, spread over the remaining MFMAs
+                constexpr int NMF = 9 * MB * NB;
+                constexpr int EPH = (kGateSteps + (NMF - BPW) - 1) / (NMF - BPW);  // steps per MFMA
+                static_assert(NMF > BPW, "a stage needs more multiply steps than weight pieces per wave");
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < BPW) {
+                    // a wave without a piece in this round repeats its previous one (same bytes to the same
+                    // place); after the last stage the other slot receives the current weights again, unused
+                    const int kq = wave + kNW * i;
+                    const int kk = kq < G::B_PIECES ? kq : kq - kNW;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(nbuf + G::A_BYTES + kk * 1024),
+                                                             16, kk * 1024 + lane * 16, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPH; ++e) {
+                        const int st = (i - BPW) * EPH + e;
+                        if (st < kGateSteps) gate_step(st, sn, nbuf, rx, more, more2, ra2, rt2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
 #ifndef SRMI_BULK_ISSUE
             if (i % GAP == GAP - 1 && i / GAP < PPW) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    if (GATE && i / GAP < APW) gate_fetch(ra, rt, i / GAP < APW ? i / GAP : 0);
-                    else issue_piece(ra, rb, nbuf, i / GAP);
-                }
+                if (more) issue_piece(ra, rb, nbuf, i / GAP);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
@@ -897,15 +949,13 @@ __global__ __launch_bounds__(64 * kNW, (ConvGeom<MB, NB>::MIN_WAVES)) void conv3
         mma_frag(f0, 1, after);
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if constexpr (GATE) {
-            if (more) gate_commit(sn, nbuf);
-        }
         STAMP();
         cur = cur + 1 == G::NS ? 0 : cur + 1;
     }
     }  // classic loop
     // the epilogue reuses the stage buffers (bias, channel sums): all waves must be out of the main loop
-    // first
+    // first (and the unused requests of a gated input's last stages must have landed)
+    if constexpr (GATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef SRMI_STAMPS_EPI
     STAMP();
