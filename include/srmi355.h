@@ -145,6 +145,20 @@ typedef struct {
     float gate_alpha;
     int32_t reserved;
     srmi_tensor_t in_sum;
+    /* Channel attention finished inside the convolution (CALayer, rcan_model.py:61-76): with ca.sums set, every
+     * workgroup adds its tile's channel sums, as 44.20 fixed point, to sums[n][c] (integer adds: the total does
+     * not depend on their order), and the workgroup that finishes an image last computes
+     *   s = sigmoid(W2 relu(W1 (sums / (h*w)) + b1) + b2)  -> scale[n][c]
+     * and clears sums[n][.] and count[n] again.  sums (uint64[n][cout]) and count (uint32[n]) must be zero before
+     * the launch; w1: float[cr][cout], w2: float[cout][cr] (device).  Excludes `chansum`; cout <= 512. */
+    struct {
+        uint64_t* sums;
+        uint32_t* count;
+        const float *w1, *b1, *w2, *b2;
+        float* scale;
+        int32_t cr;
+        int32_t reserved;
+    } ca;
 } srmi_conv_desc_t;
 
 int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream);

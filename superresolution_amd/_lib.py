@@ -47,7 +47,10 @@ class ConvDesc(C.Structure):
                 ("tail_lo", C.c_float), ("tail_hi", C.c_float), ("tail_scale", C.c_float),
                 ("tail_round", C.c_int32), ("wscale", C.c_void_p),
                 ("in_gate", Tensor), ("gate", C.c_void_p), ("gate_alpha", C.c_float), ("reserved", C.c_int32),
-                ("in_sum", Tensor)]
+                ("in_sum", Tensor),
+                ("ca_sums", C.c_void_p), ("ca_count", C.c_void_p), ("ca_w1", C.c_void_p), ("ca_b1", C.c_void_p),
+                ("ca_w2", C.c_void_p), ("ca_b2", C.c_void_p), ("ca_scale", C.c_void_p), ("ca_cr", C.c_int32),
+                ("ca_reserved", C.c_int32)]
 
 
 class ConvFirstDesc(C.Structure):

@@ -77,6 +77,13 @@ struct ConvParams {
     float alpha, beta;
     TView res1, res2, out, out2;
     float* chansum;
+    // channel attention finished by the last workgroup of an image (see srmi_conv_desc_t::ca)
+    unsigned long long* ca_sums;
+    unsigned* ca_count;
+    const float *ca_w1, *ca_b1, *ca_w2, *ca_b2;
+    float* ca_scale;
+    int ca_cr;
+    float ca_inv_hw;
     void* tail_out;
     float tail_mat[9];
     float tail_bias[3];

@@ -224,8 +224,9 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 for (int j = 0; j < 4; ++j) { scale_r[b][q][j] = s0[j]; scale_r[b][q][4 + j] = s1[j]; }
             }
     }
+    const bool want_sums = p.chansum != nullptr || p.ca_sums != nullptr;
     float csum[NB][2][8];
-    if (p.chansum) {
+    if (want_sums) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -384,7 +385,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 }
             }
         }
-        if (p.chansum) {
+        if (want_sums) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -410,7 +411,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
         }
     }
 
-    if (p.chansum) {
+    if (want_sums) {
         // deterministic tile sums: lanes -> wave (DPP adds inside each 32-lane half), waves -> LDS
         // (lds_red aliases the stage buffers, which nobody reads any more)
 #pragma unroll
@@ -430,8 +431,56 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 s += (lds_red[wv * 32 * NB + k.tid] + lds_red[(wv + 1) * 32 * NB + k.tid]) +
                      (lds_red[(wv + 2) * 32 * NB + k.tid] + lds_red[(wv + 3) * 32 * NB + k.tid]);
             const int cq = k.ct * 32 * NB + k.tid;
-            if (cq < p.cout_real)
-                p.chansum[((long long)k.n * (p.tiles_x * p.tiles_y) + k.tile) * p.cout_real + cq] = s;
+            if (cq < p.cout_real) {
+                if (p.chansum) p.chansum[((long long)k.n * (p.tiles_x * p.tiles_y) + k.tile) * p.cout_real + cq] = s;
+                if (p.ca_sums) {
+                    // 44.20 fixed point: the image total is the same whatever order the tiles arrive in.  The
+                    // returned value is waited for: the add has then been performed where every other
+                    // workgroup's atomics on this address are, before this workgroup reports its arrival.
+                    const unsigned long long before =
+                        __hip_atomic_fetch_add(p.ca_sums + (long long)k.n * p.cout_real + cq, (unsigned long long)__float2ll_rn(s * 1048576.f),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::"v"(before) : "memory");
+                }
+            }
+        }
+        if (p.ca_sums) {
+            // The workgroup that arrives last for its image finds every tile's contribution in sums[n][.]: it
+            // turns them into the attention scale and leaves sums and count at zero for the next launch.
+            // Only atomics carry data between workgroups here (no fence: a release at device scope would write
+            // the whole L2 back): adds performed -> barrier -> arrival counted -> the last arrival exchanges the
+            // totals out.
+            int* flag = (int*)(lds_red + kNW * 32 * NB);
+            __syncthreads();
+            if (k.tid == 0) {
+                const unsigned total = gridDim.x * gridDim.y;
+                const unsigned old = __hip_atomic_fetch_add(p.ca_count + k.n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = old == total - 1;
+            }
+            __syncthreads();
+            if (*flag) {
+                float* mean = lds_red;                 // [cout_real]
+                float* z = lds_red + p.cout_real;      // [cr]
+                __syncthreads();
+                for (int c = k.tid; c < p.cout_real; c += 64 * kNW) {
+                    const long long v = (long long)__hip_atomic_exchange(p.ca_sums + (long long)k.n * p.cout_real + c, 0ull,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mean[c] = (float)((double)v * (1.0 / 1048576.0)) * p.ca_inv_hw;
+                }
+                __syncthreads();
+                for (int j = k.tid; j < p.ca_cr; j += 64 * kNW) {
+                    float a = p.ca_b1[j];
+                    for (int c = 0; c < p.cout_real; ++c) a += p.ca_w1[j * p.cout_real + c] * mean[c];
+                    z[j] = fmaxf(a, 0.f);
+                }
+                __syncthreads();
+                for (int c = k.tid; c < p.cout_real; c += 64 * kNW) {
+                    float a = p.ca_b2[c];
+                    for (int j = 0; j < p.ca_cr; ++j) a += p.ca_w2[c * p.ca_cr + j] * z[j];
+                    p.ca_scale[(long long)k.n * p.cout_real + c] = 1.f / (1.f + expf(-a));
+                }
+                if (k.tid == 0) __hip_atomic_store(p.ca_count + k.n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -1141,6 +1190,12 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     } else if (d->in_sum.ptr || d->gate) {
         SRMI_FAIL("srmi_conv3x3: in_sum / gate without in_gate");
     }
+    if (d->ca.sums) {
+        if (!d->ca.count || !d->ca.w1 || !d->ca.b1 || !d->ca.w2 || !d->ca.b2 || !d->ca.scale || d->ca.cr <= 0)
+            SRMI_FAIL("srmi_conv3x3: incomplete channel-attention block");
+        if (d->chansum || tail || r > 1 || d->cout > 512 || d->ca.cr > 512 || d->dtype == SRMI_I8)
+            SRMI_FAIL("srmi_conv3x3: channel attention excludes chansum, tail, pixel shuffle, int8 and cout > 512");
+    }
     if ((long long)d->h * d->w * kPixBytes * r * r >= (1ll << 32)) SRMI_FAIL("srmi_conv3x3: plane larger than 4 GiB");
 
     ConvParams p;
@@ -1168,6 +1223,10 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.res1 = to_view(d->res1); p.res2 = to_view(d->res2);
     p.out = to_view(d->out); p.out2 = to_view(d->out2);
     p.chansum = d->chansum;
+    p.ca_sums = (unsigned long long*)d->ca.sums; p.ca_count = d->ca.count;
+    p.ca_w1 = d->ca.w1; p.ca_b1 = d->ca.b1; p.ca_w2 = d->ca.w2; p.ca_b2 = d->ca.b2;
+    p.ca_scale = d->ca.scale; p.ca_cr = d->ca.cr;
+    p.ca_inv_hw = 1.f / ((float)d->h * (float)d->w);
     p.tail_out = d->tail_out;
 #if defined(SRMI_DIAG) && (defined(SRMI_STAMPS) || defined(SRMI_CLOCK))
     if (d->tail_mode == SRMI_TAIL_NONE) {

@@ -361,10 +361,19 @@ struct Exec {
         srmi_tensor_t sum;    // where the block's output is stored on the way (ptr NULL: nowhere)
     };
 
+    // channel attention finished by the conv that produces the block's body (its last workgroup per image)
+    struct Attention {
+        const CaW* w;
+        int cr;
+        uint64_t* sums;    // [ns][c], zero between launches
+        uint32_t* count;   // [ns], zero between launches
+        float* scale;      // [ns][c]
+    };
+
     int conv(const std::string& name, const srmi_tensor_t& in, int h, int w, int act, bool up2,
              float alpha, const srmi_tensor_t* res1, float beta, const srmi_tensor_t* res2,
              const srmi_tensor_t* out, const srmi_tensor_t* out2, float* chansum = nullptr, int force_mb = 0,
-             const Gate* gate = nullptr) {
+             const Gate* gate = nullptr, const Attention* att = nullptr) {
         auto it = m->convs.find(name);
         if (it == m->convs.end()) SRMI_FAIL("internal: conv '%s' not uploaded", name.c_str());
         const ConvW& cw = it->second;
@@ -383,6 +392,10 @@ struct Exec {
         if (out) d.out = *out;
         if (out2) d.out2 = *out2;
         d.chansum = chansum;
+        if (att) {
+            d.ca.sums = att->sums; d.ca.count = att->count; d.ca.scale = att->scale; d.ca.cr = att->cr;
+            d.ca.w1 = att->w->w1; d.ca.b1 = att->w->b1; d.ca.w2 = att->w->w2; d.ca.b2 = att->w->b2;
+        }
         if (gate) {
             d.in_gate = gate->body; d.gate = gate->scale; d.gate_alpha = gate->alpha; d.in_sum = gate->sum;
         }
@@ -754,10 +767,13 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
     Buf H = A.take(nf, h, w, TR);
     Buf GI[2] = {A.take(nf, h, w, TR), A.take(nf, h, w, TR)};
     const int ns = A.ns;
-    const int max_tiles = srmi_conv3x3_tiles(h, w, 2);
-    float* chansum = A.take_floats((size_t)ns * max_tiles * nf);
+    // per-image channel sums (64-bit fixed point) and arrival counters of the attention blocks: zero whenever no
+    // conv is running on them (cleared here once, then by the workgroup that consumes them)
+    uint64_t* ca_sums = (uint64_t*)A.take_floats((size_t)ns * nf * 2);
+    uint32_t* ca_count = (uint32_t*)A.take_floats((size_t)ns);
     float* scale = A.take_floats((size_t)ns * nf);
     if (ex) {
+        SRMI_HIP(hipMemsetAsync(ca_sums, 0, (size_t)((char*)scale - (char*)ca_sums), ex->stream));
         srmi_tensor_t o = tv(XT[0]), o2 = tv(H);
         if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
         char name[96];
@@ -785,10 +801,9 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
                     if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr)) return -1;
                 }
                 snprintf(name, sizeof(name), "body.%d.body.%d.body.2", g, b);
-                const int mb = pick_rows_per_wave(m, h);
-                if (ex->conv(name, t, h, w, SRMI_ACT_NONE, false, 1.f, nullptr, 1.f, nullptr, &y, nullptr, chansum, mb)) return -1;
-                const CaW& ca = m->cas[ca_index++];
-                if (srmi_ca_scale(chansum, ns, srmi_conv3x3_tiles(h, w, mb), nf, cr, h * w, ca.w1, ca.b1, ca.w2, ca.b2, scale, ex->stream)) return -1;
+                // body.2 also pools its output and, in its last workgroup, runs the squeeze / excite layers
+                const Exec::Attention att{&m->cas[ca_index++], cr, ca_sums, ca_count, scale};
+                if (ex->conv(name, t, h, w, SRMI_ACT_NONE, false, 1.f, nullptr, 1.f, nullptr, &y, nullptr, nullptr, 0, nullptr, &att)) return -1;
                 if (fused) {
                     pending = true;
                     continue;

@@ -107,11 +107,13 @@ class PackedConv:
 def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Planes = None,
             beta=1.0, res2: Planes = None, out: Planes = None, out_c0=0, out_dtype=None,
             out2: Planes = None, chansum=False, rows_per_wave=0, tail=None, out_round8=False, out_qscale=0.0,
-            in_gate: Planes = None, gate: torch.Tensor = None, gate_alpha=1.0, in_sum: Planes = None):
+            in_gate: Planes = None, gate: torch.Tensor = None, gate_alpha=1.0, in_sum: Planes = None, attention=None):
     """act(conv(x)+b)*alpha+res1 (*beta+res2) -> out (see srmi_conv3x3 in include/srmi355.h).
 
     in_gate / gate / gate_alpha: the conv reads x + gate_alpha * (in_gate * gate[n][c]) (gate: f32 [n][cin] on the
     GPU) and stores that sum to in_sum (if given).
+    attention: (w1 [cr][c], b1, w2 [c][cr], b2) of a CALayer; the conv then also returns its scale s[n][c]
+    (pooling, squeeze / excite and sigmoid finished by the last workgroup of each image).
 
     tail: None, or dict(mode=TAIL_*, mat=3x3, bias=3, lo, hi, scale, round) for the RGB layer.
     Returns out (Planes), or the tail tensor; with chansum=True returns (out, sums[n][tiles][c]).
@@ -134,6 +136,17 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
         d.in_sum = in_sum.view() if in_sum is not None else _NULL
     sums = None
     result = None
+    att_scale = None
+    if attention is not None:
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1))).cuda()
+        w1, b1, w2, b2 = (dev(a) for a in attention)
+        att_sums = torch.zeros((n, pc.cout), dtype=torch.int64, device="cuda")
+        att_count = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        att_scale = torch.empty((n, pc.cout), dtype=torch.float32, device="cuda")
+        d.ca_sums, d.ca_count, d.ca_scale = att_sums.data_ptr(), att_count.data_ptr(), att_scale.data_ptr()
+        d.ca_w1, d.ca_b1, d.ca_w2, d.ca_b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+        d.ca_cr = b1.numel()
+        keep += [w1, b1, w2, b2, att_sums, att_count]
     if tail is None:
         r = pc.ps_r
         if out is None:
@@ -164,6 +177,12 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
         d.tail_lo, d.tail_hi = tail.get("lo", 0.0), tail.get("hi", 1.0)
         d.tail_scale, d.tail_round = tail.get("scale", 255.0), tail.get("round", 0)
     check(lib().srmi_conv3x3(C.byref(d), _stream()), "conv3x3")
+    if attention is not None:
+        torch.cuda.current_stream().synchronize()
+        if int(att_sums.abs().max()) or int(att_count.abs().max()):
+            raise _lib.SrmiError("conv3x3: attention accumulators were not left at zero")
+        del keep
+        return result, att_scale
     del keep
     if chansum:
         return result, sums

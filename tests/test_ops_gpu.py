@@ -317,3 +317,29 @@ def test_gated_input_equals_ca_apply_then_conv(dt, name, mb, c, cout):
     assert_close(ref, F.relu(F.conv2d(xs, wt, b, padding=1)), 2.0 ** -10 if dt == _lib.F16 else 2.0 ** -7, f"gated {name}")
     with pytest.raises(_lib.SrmiError):
         ops.conv3x3(xp, pc, in_gate=tp, gate=gate, in_sum=xp)   # the sum may not overwrite an input
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+@pytest.mark.parametrize("c,mb", [(64, 3), (64, 2), (96, 3), (128, 3)])
+def test_attention_finished_inside_the_conv(dt, name, tol, c, mb):
+    """Pooling + squeeze / excite + sigmoid done by the conv's last workgroup per image (CALayer,
+    rcan_model.py:61-76) against the two-kernel form (tile sums, then srmi_ca_scale) and the functional reference;
+    the accumulators are left at zero (ops.conv3x3 checks it), so a second launch gives the same bits."""
+    n, h, w, cr = 3, 45, 70, max(c // 16, 1)
+    x = q(rnd("x", (n, c, h, w), 1), dt)
+    wt = q(rnd("w", (c, c, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (c,), 3)
+    w1, b1 = rnd("w1", (cr, c), 4, 0.05), rnd("b1", (cr,), 5, 0.1)
+    w2, b2 = rnd("w2", (c, cr), 6, 0.5), rnd("b2", (c,), 7, 0.1)
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=32 if c % 64 else 64)
+    xp = ops.Planes.from_nchw(x, dt)
+    out, sums = ops.conv3x3(xp, pc, chansum=True, rows_per_wave=mb)
+    two = ops.ca_scale(sums, h * w, w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy()).cpu()
+    out1, one = ops.conv3x3(xp, pc, rows_per_wave=mb, attention=(w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy()))
+    assert torch.equal(out1.to_nchw().cpu(), out.to_nchw().cpu())
+    assert float((one.cpu() - two).abs().max()) <= 2e-6, "fixed-point pooling differs from the float tile sums"
+    y = F.conv2d(x, wt, b, padding=1)
+    ref = torch.sigmoid(F.linear(F.relu(F.linear(y.mean(dim=(2, 3)), w1, b1)), w2, b2))
+    assert float((one.cpu() - ref).abs().max()) <= (1e-5 if dt == _lib.F32 else 2e-4)
+    _, again = ops.conv3x3(xp, pc, rows_per_wave=mb, attention=(w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy()))
+    assert torch.equal(again.cpu(), one.cpu())
