@@ -81,6 +81,7 @@ typedef struct {
  * draw measurably less power on operands with short significands, so tensors that tolerate it (the
  * grown channels x1..x4 of a dense block, realesrgan_model.py:27-30) are kept that way. */
 #define SRMI_TENSOR_ROUND8 1
+#define SRMI_CA_SLOTS 8   /* accumulators per image and channel of srmi_conv_desc_t::ca */
 
 /*
  * 3x3, stride 1, zero-padding 1 convolution with fused epilogue; replaces
@@ -146,10 +147,10 @@ typedef struct {
     int32_t reserved;
     srmi_tensor_t in_sum;
     /* Channel attention finished inside the convolution (CALayer, rcan_model.py:61-76): with ca.sums set, every
-     * workgroup adds its tile's channel sums, as 44.20 fixed point, to sums[n][c] (integer adds: the total does
-     * not depend on their order), and the workgroup that finishes an image last computes
+     * workgroup adds its tile's channel sums, as 44.20 fixed point, to sums[n][tile % SRMI_CA_SLOTS][c] (integer
+     * adds: the total does not depend on their order), and the workgroup that finishes an image last computes
      *   s = sigmoid(W2 relu(W1 (sums / (h*w)) + b1) + b2)  -> scale[n][c]
-     * and clears sums[n][.] and count[n] again.  sums (uint64[n][cout]) and count (uint32[n]) must be zero before
+     * and clears sums[n] and count[n] again.  sums (uint64[n][SRMI_CA_SLOTS][cout]) and count (uint32[n]) must be zero before
      * the launch; w1: float[cr][cout], w2: float[cout][cr] (device).  Excludes `chansum`; cout <= 512. */
     struct {
         uint64_t* sums;

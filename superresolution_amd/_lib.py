@@ -32,6 +32,7 @@ class Tensor(C.Structure):
 
 
 TENSOR_ROUND8 = 1
+CA_SLOTS = 8   # SRMI_CA_SLOTS
 
 
 class ConvDesc(C.Structure):

@@ -437,9 +437,11 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                     // 44.20 fixed point: the image total is the same whatever order the tiles arrive in.  The
                     // returned value is waited for: the add has then been performed where every other
                     // workgroup's atomics on this address are, before this workgroup reports its arrival.
-                    const unsigned long long before =
-                        __hip_atomic_fetch_add(p.ca_sums + (long long)k.n * p.cout_real + cq, (unsigned long long)__float2ll_rn(s * 1048576.f),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // Neighbouring tiles finish together and atomics on one address run one after the other: tiles
+                    // are spread over SRMI_CA_SLOTS accumulators per channel.
+                    const unsigned long long before = __hip_atomic_fetch_add(
+                        p.ca_sums + ((long long)k.n * SRMI_CA_SLOTS + (k.tile & (SRMI_CA_SLOTS - 1))) * p.cout_real + cq,
+                        (unsigned long long)__float2ll_rn(s * 1048576.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::"v"(before) : "memory");
                 }
             }
@@ -463,9 +465,16 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 float* z = lds_red + p.cout_real;      // [cr]
                 __syncthreads();
                 for (int c = k.tid; c < p.cout_real; c += 64 * kNW) {
-                    const long long v = (long long)__hip_atomic_exchange(p.ca_sums + (long long)k.n * p.cout_real + c, 0ull,
-                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    mean[c] = (float)((double)v * (1.0 / 1048576.0)) * p.ca_inv_hw;
+                    unsigned long long* slot0 = p.ca_sums + (long long)k.n * SRMI_CA_SLOTS * p.cout_real + c;
+                    long long v[SRMI_CA_SLOTS];
+#pragma unroll
+                    for (int u = 0; u < SRMI_CA_SLOTS; ++u)
+                        v[u] = (long long)__hip_atomic_exchange(slot0 + (long long)u * p.cout_real, 0ull, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                    long long total = 0;
+#pragma unroll
+                    for (int u = 0; u < SRMI_CA_SLOTS; ++u) total += v[u];
+                    mean[c] = (float)((double)total * (1.0 / 1048576.0)) * p.ca_inv_hw;
                 }
                 __syncthreads();
                 for (int j = k.tid; j < p.ca_cr; j += 64 * kNW) {

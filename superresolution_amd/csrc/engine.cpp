@@ -365,7 +365,7 @@ struct Exec {
     struct Attention {
         const CaW* w;
         int cr;
-        uint64_t* sums;    // [ns][c], zero between launches
+        uint64_t* sums;    // [ns][SRMI_CA_SLOTS][c], zero between launches
         uint32_t* count;   // [ns], zero between launches
         float* scale;      // [ns][c]
     };
@@ -769,7 +769,7 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
     const int ns = A.ns;
     // per-image channel sums (64-bit fixed point) and arrival counters of the attention blocks: zero whenever no
     // conv is running on them (cleared here once, then by the workgroup that consumes them)
-    uint64_t* ca_sums = (uint64_t*)A.take_floats((size_t)ns * nf * 2);
+    uint64_t* ca_sums = (uint64_t*)A.take_floats((size_t)ns * SRMI_CA_SLOTS * nf * 2);
     uint32_t* ca_count = (uint32_t*)A.take_floats((size_t)ns);
     float* scale = A.take_floats((size_t)ns * nf);
     if (ex) {

@@ -140,7 +140,7 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
     if attention is not None:
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1))).cuda()
         w1, b1, w2, b2 = (dev(a) for a in attention)
-        att_sums = torch.zeros((n, pc.cout), dtype=torch.int64, device="cuda")
+        att_sums = torch.zeros((n, _lib.CA_SLOTS, pc.cout), dtype=torch.int64, device="cuda")
         att_count = torch.zeros((n,), dtype=torch.int32, device="cuda")
         att_scale = torch.empty((n, pc.cout), dtype=torch.float32, device="cuda")
         d.ca_sums, d.ca_count, d.ca_scale = att_sums.data_ptr(), att_count.data_ptr(), att_scale.data_ptr()
