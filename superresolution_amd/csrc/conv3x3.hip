@@ -1109,7 +1109,7 @@ static int launch(const ConvParams& p, hipStream_t stream) {
 template <int DT>
 static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
     if constexpr (DT == SRMI_I8) {  // dense-block shapes only: 32-wide output tiles, 8- or 12-row tiles
-        if (nb != 1 || mb == 4) SRMI_FAIL("srmi_conv3x3: int8 needs cout_tile 32 and rows_per_wave 2 or 3");
+        if (nb != 1 || mb >= 4) SRMI_FAIL("srmi_conv3x3: int8 needs cout_tile 32 and rows_per_wave 2 or 3");
         return mb == 2 ? launch<DT, 2, 1>(p, s) : launch<DT, 3, 1>(p, s);
     }
     if constexpr (DT == SRMI_F16 || DT == SRMI_BF16) {
@@ -1193,7 +1193,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     if (d->in_gate.ptr) {
         if (d->dtype != SRMI_F16 && d->dtype != SRMI_BF16) SRMI_FAIL("srmi_conv3x3: a gated input needs f16 or bf16 compute");
         if (d->in_gate.dtype != d->dtype || !d->gate) SRMI_FAIL("srmi_conv3x3: in_gate must be of the compute dtype and come with a gate vector");
-        if (d->in_up2 || d->cin > 256 || mb > 3) SRMI_FAIL("srmi_conv3x3: a gated input excludes in_up2, cin > 256 and rows_per_wave 4");
+        if (d->in_up2 || d->cin > 256 || mb > 3) SRMI_FAIL("srmi_conv3x3: a gated input excludes in_up2, cin > 256 and rows_per_wave above 3");
         if (d->in_sum.ptr && (d->in_sum.dtype != d->dtype || d->in_sum.ptr == d->in.ptr || d->in_sum.ptr == d->in_gate.ptr))
             SRMI_FAIL("srmi_conv3x3: in_sum must be a separate tensor of the compute dtype");
     } else if (d->in_sum.ptr || d->gate) {
@@ -1237,6 +1237,12 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.ca_scale = d->ca.scale; p.ca_cr = d->ca.cr;
     p.ca_inv_hw = 1.f / ((float)d->h * (float)d->w);
     p.tail_out = d->tail_out;
+#ifdef SRMI_DIAG
+    // timing ablations (wrong results): every input plane aliases plane 0 / every output plane aliases plane 0,
+    // which removes most of the memory traffic and leaves the matrix work as it is
+    if (getenv("SRMI_ABL_ALIAS_IN")) p.in.plane_stride_b = 0;
+    if (getenv("SRMI_ABL_ALIAS_OUT")) { p.out.plane_stride_b = 0; p.out2.plane_stride_b = 0; }
+#endif
 #if defined(SRMI_DIAG) && (defined(SRMI_STAMPS) || defined(SRMI_CLOCK))
     if (d->tail_mode == SRMI_TAIL_NONE) {
         p.tail_out = getenv("SRMI_STAMP_PTR") ? (void*)strtoull(getenv("SRMI_STAMP_PTR"), nullptr, 0) : nullptr;

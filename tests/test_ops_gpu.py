@@ -52,6 +52,25 @@ def test_conv_64_64_relu(dt, name, tol, mb):
 
 
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
+@pytest.mark.parametrize("mb", [4])
+def test_conv_tall_tiles_32_outputs(dt, name, tol, mb):
+    """16-row tiles (32-output workgroups only): ragged bottom and right edges, LeakyReLU, a residual."""
+    n, h, w = 2, 53, 75
+    x = q(rnd("x", (n, 96, h, w), 1), dt)
+    wt = q(rnd("w", (64, 96, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (64,), 3)
+    r1 = q(rnd("r1", (n, 64, h, w), 4), dt)
+    ref = F.leaky_relu(F.conv2d(x, wt, b, padding=1), 0.2) * 0.2 + r1
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=32)
+    out = ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, act=_lib.ACT_LRELU, rows_per_wave=mb, alpha=0.2,
+                      res1=ops.Planes.from_nchw(r1, dt))
+    assert_close(out.to_nchw().cpu(), ref, tol, f"conv {name} mb={mb}")
+    ref3 = ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, act=_lib.ACT_LRELU, rows_per_wave=3, alpha=0.2,
+                       res1=ops.Planes.from_nchw(r1, dt))
+    assert torch.equal(out.to_nchw().cpu(), ref3.to_nchw().cpu()), "tile height changes the result"
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
 def test_rdb_conv5_two_residuals(dt, name, tol):
     # x5*0.2 + x, then *0.2 + R  (realesrgan_model.py:32,49); trunk copies in f32
     n, h, w = 1, 21, 70
