@@ -42,7 +42,7 @@
 // passes -DSRMI_DIAG with them); the shipped library is built without any of them.
 #if !defined(SRMI_DIAG) && (defined(SRMI_ABL_NO_DMA) || defined(SRMI_ABL_NO_DMA_A) || defined(SRMI_ABL_NO_DMA_B) || \
                             defined(SRMI_ABL_NO_LDS) || defined(SRMI_STAMPS) || defined(SRMI_BULK_ISSUE) ||          \
-                            defined(SRMI_SINGLE_FRAG) || defined(SRMI_NO_XCD_MAP) || defined(SRMI_CLOCK) || defined(SRMI_STAMPS_EPI) || defined(SRMI_GAP_OVERRIDE) || defined(SRMI_NW) || defined(SRMI_RING))
+                            defined(SRMI_SINGLE_FRAG) || defined(SRMI_NO_XCD_MAP) || defined(SRMI_CLOCK) || defined(SRMI_STAMPS_EPI) || defined(SRMI_GAP_OVERRIDE) || defined(SRMI_NW) || defined(SRMI_RING) || defined(SRMI_ABL_DX_COPY))
 #error "diagnostic kernel variants need -DSRMI_DIAG"
 #endif
 
@@ -802,6 +802,9 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
                     f.wf[rho][b] = *(const u32x4*)(Bb + ((rho * 3 + dx) * 32 * NB + b * 32) * 32 + ((lh ^ bm) << 4));
             }
             const int pp = p0 + rho * PW + dx;
+#ifdef SRMI_ABL_DX_COPY  // timing ablation (wrong results): only the first horizontal tap reads pixel fragments
+            if (dx != 0) continue;
+#endif
             f.pf[rho] = *(const u32x4*)(Ab + pp * 32 + (((lh ^ (pp >> 3)) & 1) << 4));
         }
     };
@@ -861,6 +864,10 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
         const char* Ab = smem + cur * G::STAGE_BYTES;
         const char* Bb = Ab + G::A_BYTES + lx * 32;
         load_frag(fb, Ab, Bb, 1);
+#ifdef SRMI_ABL_DX_COPY
+#pragma unroll
+        for (int rho = 0; rho < MB + 2; ++rho) fb.pf[rho] = fa.pf[rho];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mma_frag(fa, 0, none);
         mma_frag(fa, 1, none);
@@ -994,6 +1001,10 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
         mma_frag(f0, 0, after);
         __builtin_amdgcn_sched_barrier(0);
         load_frag(f1, Ab, Bb, 1);
+#ifdef SRMI_ABL_DX_COPY
+#pragma unroll
+        for (int rho = 0; rho < MB + 2; ++rho) f1.pf[rho] = f0.pf[rho];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mma_frag(f0, 1, after);
         __builtin_amdgcn_sched_barrier(0);
