@@ -140,7 +140,9 @@ typedef struct {
      * block's input, in_gate = its body before the attention scale, gate = srmi_ca_scale's result), so the block's
      * last elementwise pass over the image is folded into the convolution that consumes it (the next block's
      * first convolution, or the group's last one, rcan_model.py:104-112).  x' has the bits srmi_ca_apply would
-     * store; it is also written to in_sum (if in_sum.ptr; a tensor other than in / in_gate) for the next residual. */
+     * store; it is also written to in_sum (if in_sum.ptr; a tensor other than in / in_gate) for the next residual.
+     * `in` and in_sum are of the compute dtype, or both SRMI_F32 (a trunk kept in single precision: the convolution
+     * multiplies the half-precision cast of x', in_sum receives x' itself; rows_per_wave 2 only). */
     srmi_tensor_t in_gate;
     const float* gate;
     float gate_alpha;

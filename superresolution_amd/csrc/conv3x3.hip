@@ -514,7 +514,7 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
     }
 }
 
-template <int DT, int MB, int NB, bool GATE>
+template <int DT, int MB, int NB, int GATE>
 __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     using G = ConvGeom<MB, NB>;
@@ -598,7 +598,10 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
         }
     };
     auto pixel_rsrc = [&](int s) {
-        return make_rsrc(in_img + (long long)s * p.in.plane_stride_b, plane_bytes);
+        if constexpr (GATE == 2)  // the two f32 planes that hold the stage's 16 channels
+            return make_rsrc(in_img + (long long)(2 * s) * p.in.plane_stride_b, (unsigned)p.in.plane_stride_b + plane_bytes);
+        else
+            return make_rsrc(in_img + (long long)s * p.in.plane_stride_b, plane_bytes);
     };
     auto weight_rsrc = [&](int s) { return make_rsrc(w_tile + (size_t)s * G::B_BYTES, G::B_BYTES); };
     auto issue = [&](int s, int buf) {
@@ -613,8 +616,20 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
     // stage are fetched into registers (same per-lane offsets, out-of-image lanes read zeros from both
     // tensors), combined with the arithmetic of ca_apply_kernel and written to the stage slot with
     // ds_write; interior pixels of the tile are also stored to `in_sum`, the trunk the next block adds to.
+    // GATE == 2: `in` and `in_sum` are f32 tensors (the trunk kept in single precision): a 16-byte chunk of a stage is
+    // the whole 32-byte pixel of one f32 plane (plane 2s + chunk), fetched and stored as two 16-byte halves.
     static_assert(!GATE || (G::NS == 2 && (DT == SRMI_F16 || DT == SRMI_BF16)), "gated input: half types, two-slot ring");
-    u32x4 gx[GATE ? APW : 1], gt[GATE ? APW : 1];
+    u32x4 gx[GATE ? APW : 1], gt[GATE ? APW : 1], gx1[GATE == 2 ? APW : 1];
+    constexpr unsigned kOobF32 = 0xFFFFFF00u;  // out of range, and still so 16 bytes further
+    // f32 trunk: per-lane offset of this lane's pixel in the two-plane window of a stage
+    auto x_offset = [&](const int q) {
+        const unsigned a = aoff[q];
+        return a == SRMI_OOB_OFFSET ? kOobF32 : (a & ~31u) + ((a >> 4) & 1u) * (unsigned)p.in.plane_stride_b;
+    };
+    auto s_offset = [&](const int q) {
+        const unsigned a = aoff[q];
+        return (a & ~31u) + ((a >> 4) & 1u) * (unsigned)p.in_sum.plane_stride_b;
+    };
     unsigned keep = 0;  // bit j: piece j of this lane is an in-image pixel of the tile's interior
     const float* gate_lds = (const float*)(smem + G::LDS_BYTES);
     const char* gate_img = nullptr;
@@ -633,7 +648,23 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
     }
     auto gate_rsrc = [&](int s) { return make_rsrc(gate_img + (long long)s * p.in_gate.plane_stride_b, plane_bytes); };
     auto sum_rsrc = [&](int s) {
-        return make_rsrc(sum_img + (long long)s * p.in_sum.plane_stride_b, sum_img ? plane_bytes : 0u);
+        if constexpr (GATE == 2)
+            return make_rsrc(sum_img + (long long)(2 * s) * p.in_sum.plane_stride_b,
+                             sum_img ? (unsigned)p.in_sum.plane_stride_b + plane_bytes : 0u);
+        else
+            return make_rsrc(sum_img + (long long)s * p.in_sum.plane_stride_b, sum_img ? plane_bytes : 0u);
+    };
+    auto gate_fetch = [&](const int q, const bool really, const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rt) {
+        if constexpr (GATE == 2) {
+            const unsigned xo = really ? x_offset(q) : kOobF32;
+            gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, xo, 0, 0));
+            gx1[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, xo + 16u, 0, 0));
+            gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, really ? aoff[q] : SRMI_OOB_OFFSET, 0, 0));
+        } else if constexpr (GATE == 1) {
+            const unsigned off = really ? aoff[q] : SRMI_OOB_OFFSET;
+            gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+            gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, off, 0, 0));
+        }
     };
     // One STEP combines one channel of one piece (8 steps per piece, 8 * APW per stage).  The main loop runs
     // the steps of stage s+1 between the MFMAs of stage s, so the conversions hide under the matrix pipe;
@@ -663,14 +694,16 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
                 gg1 = *(const f32x4*)(g + 4);
             }
             float xv, tv;
-            if constexpr (DT == SRMI_F16) {
-                xv = (float)__builtin_bit_cast(f16x8, gx[q])[j];
-                tv = (float)__builtin_bit_cast(f16x8, gt[q])[j];
-            } else {
-                xv = (float)__builtin_bit_cast(bf16x8, gx[q])[j];
-                tv = (float)__builtin_bit_cast(bf16x8, gt[q])[j];
-            }
+            if constexpr (DT == SRMI_F16) tv = (float)__builtin_bit_cast(f16x8, gt[q])[j];
+            else tv = (float)__builtin_bit_cast(bf16x8, gt[q])[j];
+            if constexpr (GATE == 2) xv = __uint_as_float(j < 4 ? gx[q][j & 3] : gx1[q][j & 3]);
+            else if constexpr (DT == SRMI_F16) xv = (float)__builtin_bit_cast(f16x8, gx[q])[j];
+            else xv = (float)__builtin_bit_cast(bf16x8, gx[q])[j];
             const float o = (tv * (j < 4 ? gg0[j & 3] : gg1[j & 3])) * gate_alpha + xv;
+            if constexpr (GATE == 2) {  // the single-precision sum takes the place of x until it is stored
+                if (j < 4) gx[q][j & 3] = __float_as_uint(o);
+                else gx1[q][j & 3] = __float_as_uint(o);
+            }
             if (j & 1) {
                 if constexpr (DT == SRMI_F16) {
                     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -687,17 +720,22 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
             if (j == 7) {
                 char* dst = mine ? abuf + k * 1024 : smem + G::LDS_BYTES + 1024;
                 *(u32x4*)(dst + lane * 16) = gpk;
-                __builtin_amdgcn_raw_buffer_store_b128(gpk, rx, (live && ((keep >> q) & 1u)) ? aoff[q] : SRMI_OOB_OFFSET, 0, 0);
-                const unsigned off = fetch_next ? aoff[q] : SRMI_OOB_OFFSET;
-                gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_next, off, 0, 0));
-                gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt_next, off, 0, 0));
+                const bool store = live && ((keep >> q) & 1u);
+                if constexpr (GATE == 2) {
+                    const unsigned so = store ? s_offset(q) : kOobF32;
+                    __builtin_amdgcn_raw_buffer_store_b128(gx[q], rx, so, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(gx1[q], rx, so + 16u, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(gpk, rx, store ? aoff[q] : SRMI_OOB_OFFSET, 0, 0);
+                }
+                gate_fetch(q, fetch_next, ra_next, rt_next);
             }
         }
     };
     // vector-memory operations of this wave that are younger than the weight pieces of a stage when that stage
-    // starts: per pixel piece one in_sum store and the two loads of the next fetch
-    constexpr int kGateYounger = 3 * APW;
-    static_assert(!GATE || kGateYounger <= 12, "a gated input supports at most four pixel pieces per wave");
+    // starts: per pixel piece the in_sum store(s) and the loads of the next fetch
+    constexpr int kGateYounger = (GATE == 2 ? 5 : 3) * APW;
+    static_assert(!GATE || kGateYounger <= 63, "vmcnt counts up to 63");
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -760,10 +798,7 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
 #pragma unroll
             for (int q = APW; q < PPW; ++q) issue_piece(ra, rb, smem, q);
 #pragma unroll
-            for (int q = 0; q < APW; ++q) {
-                gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], 0, 0));
-                gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, aoff[q], 0, 0));
-            }
+            for (int q = 0; q < APW; ++q) gate_fetch(q, true, ra, rt);
         }
         __syncthreads();  // the gate vector is in LDS
         {
@@ -1093,7 +1128,7 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
 // ---- host launcher --------------------------------------------------------------------------------
 // The dynamic-LDS limit is a per-device attribute of the function: set once on every device used.  Setting
 // it twice is harmless, so concurrent first calls only need the bookkeeping itself to be atomic.
-template <int DT, int MB, int NB, bool GATE>
+template <int DT, int MB, int NB, int GATE>
 static int configure() {
     static std::atomic<unsigned long long> configured{0};
     int dev = 0;
@@ -1107,7 +1142,7 @@ static int configure() {
     return 0;
 }
 
-template <int DT, int MB, int NB, bool GATE = false>
+template <int DT, int MB, int NB, int GATE = 0>
 static int launch(const ConvParams& p, hipStream_t stream) {
     constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0);
     if (configure<DT, MB, NB, GATE>()) return -1;
@@ -1124,9 +1159,10 @@ static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
         return mb == 2 ? launch<DT, 2, 1>(p, s) : launch<DT, 3, 1>(p, s);
     }
     if constexpr (DT == SRMI_F16 || DT == SRMI_BF16) {
-        if (p.in_gate.ptr) {  // validated by the caller: rows_per_wave 2 or 3
-            if (nb == 1) return mb == 2 ? launch<DT, 2, 1, true>(p, s) : launch<DT, 3, 1, true>(p, s);
-            return mb == 2 ? launch<DT, 2, 2, true>(p, s) : launch<DT, 3, 2, true>(p, s);
+        if (p.in_gate.ptr) {  // validated by the caller: rows_per_wave 2 or 3 (2 with an f32 `in`)
+            if (p.in.dtype == SRMI_F32) return nb == 1 ? launch<DT, 2, 1, 2>(p, s) : launch<DT, 2, 2, 2>(p, s);
+            if (nb == 1) return mb == 2 ? launch<DT, 2, 1, 1>(p, s) : launch<DT, 3, 1, 1>(p, s);
+            return mb == 2 ? launch<DT, 2, 2, 1>(p, s) : launch<DT, 3, 2, 1>(p, s);
         }
     }
     if (nb == 1) {
@@ -1141,13 +1177,14 @@ static int launch_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
 
 template <int DT>
 static int configure_dt() {
-    if constexpr (DT == SRMI_I8) return configure<DT, 2, 1, false>() || configure<DT, 3, 1, false>();
+    if constexpr (DT == SRMI_I8) return configure<DT, 2, 1, 0>() || configure<DT, 3, 1, 0>();
     if constexpr (DT == SRMI_F16 || DT == SRMI_BF16) {
-        if (configure<DT, 2, 1, true>() || configure<DT, 3, 1, true>() || configure<DT, 2, 2, true>() || configure<DT, 3, 2, true>())
+        if (configure<DT, 2, 1, 1>() || configure<DT, 3, 1, 1>() || configure<DT, 2, 2, 1>() || configure<DT, 3, 2, 1>() ||
+            configure<DT, 2, 1, 2>() || configure<DT, 2, 2, 2>())
             return -1;
     }
-    return configure<DT, 2, 1, false>() || configure<DT, 3, 1, false>() || configure<DT, 4, 1, false>() ||
-           configure<DT, 2, 2, false>() || configure<DT, 3, 2, false>();
+    return configure<DT, 2, 1, 0>() || configure<DT, 3, 1, 0>() || configure<DT, 4, 1, 0>() ||
+           configure<DT, 2, 2, 0>() || configure<DT, 3, 2, 0>();
 }
 
 static int default_rows_per_wave() { return 3; }  // 12-row tiles: the fastest variant on every layer measured
@@ -1181,7 +1218,8 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     const int cpb = dtype_cpb(d->dtype);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0) SRMI_FAIL("srmi_conv3x3: bad shape n=%d h=%d w=%d", d->n, d->h, d->w);
     if (d->cin <= 0 || d->cin % cpb) SRMI_FAIL("srmi_conv3x3: cin=%d is not a multiple of %d", d->cin, cpb);
-    if (!d->in.ptr || d->in.dtype != d->dtype) SRMI_FAIL("srmi_conv3x3: input tensor missing or of another dtype");
+    const bool gated_f32 = d->in_gate.ptr && d->in.ptr && d->in.dtype == SRMI_F32 && d->dtype != SRMI_F32;
+    if (!d->in.ptr || (d->in.dtype != d->dtype && !gated_f32)) SRMI_FAIL("srmi_conv3x3: input tensor missing or of another dtype");
     if (!d->wpk || !d->bias) SRMI_FAIL("srmi_conv3x3: missing weights or bias");
     if (d->cout_tile != 32 && d->cout_tile != 64) SRMI_FAIL("srmi_conv3x3: cout_tile must be 32 or 64");
     const int mb = d->rows_per_wave ? d->rows_per_wave : default_rows_per_wave();
@@ -1205,8 +1243,10 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
         if (d->dtype != SRMI_F16 && d->dtype != SRMI_BF16) SRMI_FAIL("srmi_conv3x3: a gated input needs f16 or bf16 compute");
         if (d->in_gate.dtype != d->dtype || !d->gate) SRMI_FAIL("srmi_conv3x3: in_gate must be of the compute dtype and come with a gate vector");
         if (d->in_up2 || d->cin > 256 || mb > 3) SRMI_FAIL("srmi_conv3x3: a gated input excludes in_up2, cin > 256 and rows_per_wave above 3");
-        if (d->in_sum.ptr && (d->in_sum.dtype != d->dtype || d->in_sum.ptr == d->in.ptr || d->in_sum.ptr == d->in_gate.ptr))
-            SRMI_FAIL("srmi_conv3x3: in_sum must be a separate tensor of the compute dtype");
+        if (d->in_sum.ptr && (d->in_sum.dtype != d->in.dtype || d->in_sum.ptr == d->in.ptr || d->in_sum.ptr == d->in_gate.ptr))
+            SRMI_FAIL("srmi_conv3x3: in_sum must be a separate tensor of the type of `in`");
+        if (gated_f32 && (mb != 2 || (long long)d->h * d->w * kPixBytes * 2 >= (1ll << 32)))
+            SRMI_FAIL("srmi_conv3x3: a gated f32 input needs rows_per_wave 2 and planes below 2 GiB");
     } else if (d->in_sum.ptr || d->gate) {
         SRMI_FAIL("srmi_conv3x3: in_sum / gate without in_gate");
     }

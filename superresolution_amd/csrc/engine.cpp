@@ -781,23 +781,29 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
         int kr = 0;   // XR[kr] holds it in the trunk dtype (split mode), when trunk_in_xr
         bool trunk_in_xr = false;
         int ca_index = 0;
-        // Half-precision trunk: a block's output x + res_scale * (y * s) is never written by a pass of its own;
-        // the convolution that consumes it (the next block's first, or the group's last) forms it while
-        // loading and, where a later residual needs it, stores it on the way.
-        const bool fused = m->fuse_attention && !split && (T == SRMI_F16 || T == SRMI_BF16) && nf <= 256;
+        // A block's output x + res_scale * (y * s) is never written by a pass of its own: the convolution that
+        // consumes it (the next block's first, or the group's last) forms it while loading and, where a later
+        // residual needs it, stores it on the way (in the trunk's own precision: half, or f32 when split).
+        const bool fused = m->fuse_attention && (T == SRMI_F16 || T == SRMI_BF16) && nf <= 256 &&
+                           (!split || gate_rows_per_wave(m, h) == 2);
         for (int g = 0; g < d.n_groups; ++g) {
             const Buf& Gin = g == 0 ? H : GI[g & 1];
-            bool pending = false;  // XT[k] + res_scale * (Y * scale) is the trunk, not yet stored
+            bool pending = false;  // trunk + res_scale * (Y * scale) is the block's output, not yet stored
+            // where the trunk before the pending block lives: the compute-dtype copy, or (split) the f32 one
+            auto trunk_view = [&]() { return !split ? tv(XT[k]) : (trunk_in_xr ? tv(XR[kr]) : tv(Gin)); };
             for (int b = 0; b < d.n_blocks; ++b) {
                 snprintf(name, sizeof(name), "body.%d.body.%d.body.0", g, b);
-                const srmi_tensor_t in = tv(XT[k]), t = tv(Tm), y = tv(Y);
+                const srmi_tensor_t t = tv(Tm), y = tv(Y);
                 if (pending) {
-                    const Exec::Gate gate{y, scale, d.res_scale, tv(XT[k ^ 1])};
+                    const srmi_tensor_t in = trunk_view();
+                    const Exec::Gate gate{y, scale, d.res_scale, split ? tv(XR[kr ^ 1]) : tv(XT[k ^ 1])};
                     if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr, nullptr,
                                  gate_rows_per_wave(m, h), &gate)) return -1;
-                    k ^= 1;
+                    if (split) { kr ^= 1; trunk_in_xr = true; }
+                    else k ^= 1;
                     pending = false;
                 } else {
+                    const srmi_tensor_t in = tv(XT[k]);
                     if (ex->conv(name, in, h, w, SRMI_ACT_RELU, false, 1.f, nullptr, 1.f, nullptr, &t, nullptr)) return -1;
                 }
                 snprintf(name, sizeof(name), "body.%d.body.%d.body.2", g, b);
@@ -809,9 +815,7 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
                     continue;
                 }
                 // x + res_scale * (y * s)   (rcan_model.py:94-97)
-                srmi_tensor_t xres;
-                if (!split) xres = tv(XT[k]);
-                else xres = trunk_in_xr ? tv(XR[kr]) : tv(Gin);
+                const srmi_tensor_t xres = trunk_view();
                 const srmi_tensor_t o1 = tv(XT[k ^ 1]);
                 srmi_tensor_t o2b = split ? tv(XR[kr ^ 1]) : srmi_tensor_t{};
                 if (srmi_ca_apply(&y, &xres, scale, d.res_scale, ns, h, w, nf, &o1, split ? &o2b : nullptr, ex->stream)) return -1;
@@ -820,12 +824,14 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
             }
             // group tail conv + group input (rcan_model.py:109-112); its output is the next group's input
             snprintf(name, sizeof(name), "body.%d.body.%d", g, d.n_blocks);
-            const srmi_tensor_t in = tv(XT[k]), res = tv(Gin), o1 = tv(XT[k ^ 1]), og = tv(GI[(g + 1) & 1]);
+            const srmi_tensor_t res = tv(Gin), o1 = tv(XT[k ^ 1]), og = tv(GI[(g + 1) & 1]);
             if (pending) {
+                const srmi_tensor_t in = trunk_view();
                 const Exec::Gate gate{tv(Y), scale, d.res_scale, srmi_tensor_t{}};
                 if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, &og, nullptr,
                              gate_rows_per_wave(m, h), &gate)) return -1;
             } else {
+                const srmi_tensor_t in = tv(XT[k]);
                 if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, &og)) return -1;
             }
             k ^= 1;

@@ -336,6 +336,17 @@ def test_gated_input_equals_ca_apply_then_conv(dt, name, mb, c, cout):
     assert_close(ref, F.relu(F.conv2d(xs, wt, b, padding=1)), 2.0 ** -10 if dt == _lib.F16 else 2.0 ** -7, f"gated {name}")
     with pytest.raises(_lib.SrmiError):
         ops.conv3x3(xp, pc, in_gate=tp, gate=gate, in_sum=xp)   # the sum may not overwrite an input
+    if mb == 2:
+        # single-precision trunk: x and the stored sum are f32 tensors, the conv input is their half-precision cast
+        x32 = rnd("x32", (n, c, h, w), 6)
+        xp32 = ops.Planes.from_nchw(x32, _lib.F32)
+        s16, s32 = ops.ca_apply(tp, xp32, gate, 0.7, out_dtype=dt, out2_dtype=_lib.F32)
+        ref = ops.conv3x3(s16, pc, act=_lib.ACT_RELU, rows_per_wave=mb).to_nchw().cpu()
+        sum32 = ops.Planes(n, c, h, w, _lib.F32, zero=True)
+        got = ops.conv3x3(xp32, pc, act=_lib.ACT_RELU, rows_per_wave=mb, in_gate=tp, gate=gate, gate_alpha=0.7, in_sum=sum32)
+        torch.cuda.synchronize()
+        assert torch.equal(sum32.to_nchw().cpu(), s32.to_nchw().cpu()), f"{name}: stored f32 sum differs"
+        assert torch.equal(got.to_nchw().cpu(), ref), f"{name}: gated conv with an f32 trunk differs"
 
 
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
