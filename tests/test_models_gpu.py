@@ -319,6 +319,40 @@ def test_edsr_widths_that_are_not_multiples_of_64(n_feats, scale):
     assert y.shape == (1, 3, 19 * scale, 27 * scale) and err <= H.f32_tol(meta)
 
 
+@pytest.mark.parametrize("n_feats,reduction", [(96, 16), (32, 8), (128, 16)])
+def test_rcan_widths_and_fused_attention(n_feats, reduction):
+    """RCAN at feature counts other than 64: 32-wide output tiles (three channel tiles per image take tickets in the
+    attention tail), two-stage and eight-stage gated convolutions.  f32 against the oracle; f16 with either trunk
+    precision gives the same bytes with and without the gated input, in one batch and frame by frame."""
+    from superresolution_amd import RCAN
+    n_groups, n_blocks, scale, h, w = 2, 3, 2, 27, 41
+    sd = synth.rcan_state_dict(scale=scale, n_resgroups=n_groups, n_resblocks=n_blocks, n_feats=n_feats, reduction=reduction, seed=93)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    kw = dict(scale=scale, n_resgroups=n_groups, n_resblocks=n_blocks, n_feats=n_feats, reduction=reduction)
+    imgs = synth.random_image(h, w, 94, n=3)
+    x = O.pre_raw(imgs)
+    m32 = RCAN(compute_dtype="f32", **kw)
+    m32.load_state_dict(tsd, strict=True)
+    with torch.no_grad():
+        ref = O.rcan_forward(sd, x, scale=scale, n_resgroups=n_groups, n_resblocks=n_blocks, res_scale=1.0).numpy()
+    err = np.abs(m32(x).numpy() - ref).max()
+    print(f"rcan n_feats={n_feats}: f32 max-abs {err:.3e}")
+    assert err <= 1e-3
+    ref_u8 = O.post_range(torch.from_numpy(ref), O.ROUND_HALF_UP)
+    for trunk_f32 in (False, True):
+        m = RCAN(compute_dtype="f16", trunk_f32=trunk_f32, **kw)
+        m.load_state_dict(tsd, strict=True)
+        eng = m.engine()
+        batch = torch.from_numpy(imgs).cuda()
+        fused = eng.forward_u8(batch, _lib.ROUND_HALF_UP).cpu().numpy()
+        one_by_one = np.concatenate([eng.forward_u8(batch[i:i + 1], _lib.ROUND_HALF_UP).cpu().numpy() for i in range(3)])
+        eng.set_fused_attention(False)
+        plain = eng.forward_u8(batch, _lib.ROUND_HALF_UP).cpu().numpy()
+        assert np.array_equal(fused, plain) and np.array_equal(fused, one_by_one), f"trunk_f32={trunk_f32}"
+        diff = np.abs(fused.astype(np.int32) - ref_u8.astype(np.int32))
+        assert diff.max() <= 1 and O.psnr_u8(fused, ref_u8) >= 50.0
+
+
 def test_caller_supplied_out_tensor_is_validated():
     """`out=` goes to the kernels as a raw pointer: a tensor of another shape, type or layout must be refused."""
     meta = dict(arch="rrdbnet", num_block=1, scale=4, seed=92, input="unit")
