@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--plain-f16", action="store_true",
                     help="RRDBNet f16: keep 11 significant bits in the dense blocks' grown channels too "
                          "(default: 8 there, srmi_model_set_growth_round8)")
+    ap.add_argument("--frames", default="mixed", choices=["mixed", "noise", "smooth"],
+                    help="synthetic input: uniform-noise frames plus one smooth frame (default), noise only, smooth only")
     ap.add_argument("--no-fused-attention", action="store_true",
                     help="RCAN: separate elementwise pass per channel-attention block instead of the gated conv input")
     ap.add_argument("--w8a8", action="store_true",
@@ -280,8 +282,12 @@ def main():
                                         [synth.random_image(h, w, 950 + i) for i in range(2)]), batch=3)
     eng = engs[0]
     scale = eng.scale
-    imgs = torch.from_numpy(synth.random_image(h, w, 100 + rank, n=batch)).cuda()
-    imgs[0] = torch.from_numpy(synth.smooth_image(h, w, rank)).cuda()
+    if args.frames == "smooth":
+        imgs = torch.from_numpy(np.stack([synth.smooth_image(h, w, 1000 * rank + i) for i in range(batch)])).cuda()
+    else:
+        imgs = torch.from_numpy(synth.random_image(h, w, 100 + rank, n=batch)).cuda()
+        if args.frames == "mixed":
+            imgs[0] = torch.from_numpy(synth.smooth_image(h, w, rank)).cuda()
     out = torch.empty((batch, h * scale, w * scale, 3), dtype=torch.uint8, device="cuda")
     streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
     main_stream = torch.cuda.current_stream()
