@@ -183,6 +183,60 @@ def side_config(arch, dtype, h, w, batch, steps, device, lanes=3):
     return rec
 
 
+def tiled_1080p_config(steps, device, tile_h=540, tile_w=480, halo=32, lanes=3):
+    """BASELINE configuration 5 on one GPU: RealESRGAN_x4plus on 1920x1080 frames -> 7680x4320, (i) whole frames
+    through the lanes and (ii) one frame as a 2 x 4 grid of halo-overlapped tiles (the unit the multi-GPU tile mode
+    shards, superresolution_amd/sharding.py; tiles of equal crop shape share a call), with the tiled frame's PSNR
+    against the whole one.  Algorithmic FLOPs are those of the frame: halo recompute is not counted as work."""
+    from superresolution_amd import _lib, sharding, synth
+    h, w = 1080, 1920
+    model, _ = build_model("rrdbnet", "f16", False, device)
+    eng = model.engine()
+    eng.set_lanes(lanes)
+    imgs = torch.from_numpy(synth.random_image(h, w, 500, n=3)).cuda()
+    imgs[0] = torch.from_numpy(synth.smooth_image(h, w, 5)).cuda()
+    out = torch.empty((3, h * 4, w * 4, 3), dtype=torch.uint8, device="cuda")
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(n):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / 1e3 / n
+
+    flops = eng.flops(h, w)
+    mpix = h * 4 * w * 4 / 1e6
+    t_whole = timed(lambda: eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out), steps) / 3
+    whole0 = out[0].clone()
+    fwd = lambda t: eng.forward_u8(t, _lib.ROUND_HALF_UP)
+    tiled = [None]
+
+    def run_tiled():
+        tiled[0] = sharding.upscale_tiled_batched(fwd, imgs[0], 4, tile_h, tile_w, halo)
+
+    t_tiled = timed(run_tiled, steps)
+    a, b = whole0.cpu().numpy().astype(np.float64), tiled[0].cpu().numpy().astype(np.float64)
+    psnr = float(10 * np.log10(255.0 ** 2 / max(np.mean((a - b) ** 2), 1e-12)))
+    crop_px = sum((t.py1 - t.py0) * (t.px1 - t.px0) for t in sharding.tile_grid(h, w, tile_h, tile_w, halo))
+    rec = {}
+    for name, t, extra in (("whole", t_whole, {"workload": "rrdbnet x4 1920x1080->7680x4320, whole frames, batch 3"}),
+                           ("tiled", t_tiled, {"workload": f"rrdbnet x4 1920x1080->7680x4320, one frame as 2x4 tiles of "
+                                                           f"{tile_w}x{tile_h} + {halo}-px halo, stitched on the GPU",
+                                               "computed_over_useful_pixels": round(crop_px / (h * w), 4),
+                                               "psnr_vs_whole_frame_db": round(psnr, 2),
+                                               "max_u8_diff_vs_whole_frame": int(np.abs(a - b).max())})):
+        rec[name] = dict(extra, dtype="f16", value=round(mpix / t, 2), unit="Mpix/s", ms_per_frame=round(t * 1e3, 3),
+                         roofline={"bound": "mfma", "achieved": round(flops / t / 1e12, 1), "peak": MFMA_PEAK_TFLOPS["f16"],
+                                   "unit": "TFLOP/s", "frac": round(flops / t / 1e12 / MFMA_PEAK_TFLOPS["f16"], 4)})
+    del eng, model
+    torch.cuda.empty_cache()
+    return rec
+
+
 def host_path(eng, h, w, batch, steps, rank):
     """The reference API's shape (host u8 image in, host u8 image out; realesrgan.cpp:217-257), PCIe transfers and
     host copies included: srmi_model_forward_u8_host on pageable numpy frames, wall clock."""
@@ -236,6 +290,10 @@ def main():
     ap.add_argument("--w8a8", action="store_true",
                     help="RRDBNet: calibrate on synthetic frames and run the dense blocks in int8 (a lower-precision "
                          "configuration of its own; never the headline)")
+    ap.add_argument("--tiles", type=int, default=0, metavar="HALO",
+                    help="tile mode (BASELINE configuration 5): every step is ONE 1920x1080 frame cut into a 2 x 4 grid of "
+                         "480x540 tiles with HALO low-resolution pixels of overlap, the tiles sharded over the ranks and the "
+                         "u8 results gathered to rank 0 (the only collective); total work is fixed: strong scaling")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier and the max-over-ranks reduce (gloo: rehearsal of the "
                          "multi-rank path on a box with fewer GPUs than ranks; ranks then share devices)")
@@ -263,6 +321,10 @@ def main():
     # workload: Real-ESRGAN x4plus on 510x339 frames is the headline configuration; the others are selectable
     defaults = {"rrdbnet": (339, 510, 12), "rcan": (339, 510, 12), "edsr": (256, 256, 36)}
     h, w, batch = defaults[args.model]
+    if args.tiles:
+        if args.model == "rcan":
+            raise SystemExit("RCAN pools over the whole frame: it cannot be tiled (replicas only)")
+        h, w, batch = 1080, 1920, 1
     h = args.height or h
     w = args.width or w
     batch = args.batch or batch
@@ -293,6 +355,10 @@ def main():
     main_stream = torch.cuda.current_stream()
 
     def step():
+        if args.tiles:
+            from superresolution_amd import sharding
+            return sharding.upscale_tiled_sharded(lambda t: eng.forward_u8(t, _lib.ROUND_HALF_UP), imgs[0], scale,
+                                                  540, 480, args.tiles, rank, world, batched=True)
         if streams is None:
             eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
             return
@@ -331,7 +397,7 @@ def main():
 
     # serial pass for the per-launch roofline figure: one lane, launches back to back
     serial = None
-    if rank == 0 and args.streams == 1:
+    if rank == 0 and args.streams == 1 and not args.tiles:
         eng.set_lanes(1)
         eng.forward_u8(imgs[:2], _lib.ROUND_HALF_UP, out=out[:2])
         torch.cuda.synchronize()
@@ -345,16 +411,17 @@ def main():
         eng.set_lanes(args.lanes)
 
     if rank == 0:
-        frames = batch * args.steps * world
+        frames = args.steps if args.tiles else batch * args.steps * world
         out_mpix = frames * (h * scale) * (w * scale) / 1e6
         flops_frame = eng.flops(h, w)
         launches = conv_launches_per_frame(models[0])
-        achieved = flops_frame * batch * args.steps / dev_s / 1e12  # per GPU
+        achieved = flops_frame * frames / world / dev_s / 1e12  # per GPU; halo recompute is not counted as work
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         if args.w8a8:
             peak = w8a8_peak(models[0], flops_frame, h, w)
         rec = {
-            "metric": "output Mpix/sec, RealESRGAN_x4plus 510x339->x4" if args.model == "rrdbnet"
+            "metric": f"output Mpix/sec, {args.model} x4 1920x1080 frame in halo tiles" if args.tiles else
+                      "output Mpix/sec, RealESRGAN_x4plus 510x339->x4" if args.model == "rrdbnet"
                       else f"output Mpix/sec, {args.model} x4",
             "value": round(out_mpix / wall, 3),
             "unit": "Mpix/s",
@@ -363,12 +430,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.tiles else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (seeded uniform u8 frames + one smooth frame; hash-generated weights in the "
                     "official state_dict layout)",
-            "config": {"workload": f"{args.model} x{scale} {w}x{h}->{w * scale}x{h * scale}, "
+            "config": {"workload": (f"{args.model} x{scale} {w}x{h}->{w * scale}x{h * scale}, one frame per step as 2x4 tiles "
+                                    f"of 480x540 + {args.tiles}-px halo sharded over the ranks, u8 tiles gathered to rank 0")
+                                   if args.tiles else
+                                   f"{args.model} x{scale} {w}x{h}->{w * scale}x{h * scale}, "
                                    f"{batch} frames per GPU per step, u8 in HBM -> u8 in HBM",
                        "frames_per_gpu_per_step": batch, "sweep": args.sweep, "lanes": args.lanes,
                        "streams": args.streams,
@@ -380,7 +450,8 @@ def main():
                         "conv1-4 / grown columns of conv5 carry 8 significant bits")
                        if (args.model == "rrdbnet" and args.dtype == "f16" and not args.plain_f16)
                        else f"{args.dtype} operands, f32 accumulation",
-                       "parallelism": f"frame-sharded x{world}, no collective"},
+                       "parallelism": f"tile-sharded x{world}, one gather of u8 tiles per frame" if args.tiles
+                                      else f"frame-sharded x{world}, no collective"},
             "ms_per_frame_per_gpu": round(dev_s / (batch * args.steps) * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.model, args.dtype),
@@ -395,7 +466,7 @@ def main():
                                          "frac": round(flops_frame / serial / 1e12 / peak, 4),
                                          "avg_launch_us": round(serial / launches * 1e6, 3),
                                          "note": "one lane: launches run back to back, as under rocprofv3 --kernel-trace"}
-        if not args.no_side_configs and world == 1 and args.model == "rrdbnet" and args.streams == 1:
+        if not args.no_side_configs and world == 1 and args.model == "rrdbnet" and args.streams == 1 and not args.tiles:
             hp = host_path(eng, h, w, batch, max(2, args.steps // 4), rank)
             hp["frac_of_hbm_resident_rate"] = round(hp["value"] / rec["value"], 3)
             rec["e2e_host"] = hp
@@ -407,7 +478,10 @@ def main():
                 "rcan_x4_510x339_f16": side_config("rcan", "f16", 339, 510, 12, side_steps, local_rank),
                 "rrdbnet_x4_510x339_w8a8": w8a8_config(339, 510, 12, side_steps, local_rank),
             }
-        if not args.no_cpu_baseline and world == 1:
+            big = tiled_1080p_config(max(1, side_steps // 2), local_rank)
+            rec["other_configs"]["rrdbnet_x4_1080p_whole_f16"] = big["whole"]
+            rec["other_configs"]["rrdbnet_x4_1080p_tiled_2x4_halo32_f16"] = big["tiled"]
+        if not args.no_cpu_baseline and world == 1 and not args.tiles:
             # 16 = the CPU share of a one-GPU box of this pool (its OMP_NUM_THREADS); os.cpu_count() there reports
             # the whole machine.  On a smaller host all cores are used.
             threads = min(16, os.cpu_count() or 1)

@@ -72,15 +72,45 @@ def upscale_tiled(forward_u8, img: torch.Tensor, scale: int, tile_h: int, tile_w
     return stitch(tiles, [upscale_tile(forward_u8, img, t, scale) for t in tiles], h, w, scale)
 
 
+def upscale_tiles_batched(forward_u8, img: torch.Tensor, tiles: Sequence[Tile], scale: int) -> List[torch.Tensor]:
+    """Upscaled cores of `tiles`, in order.  Tiles whose crops have the same shape (interior tiles; edge tiles
+    of one kind) are stacked and go through the network in one call, so that the engine's stream lanes overlap
+    them; every frame of a batch is computed exactly as it would be alone, so the result equals
+    [upscale_tile(...) for t in tiles]."""
+    groups = {}
+    for i, t in enumerate(tiles):
+        groups.setdefault((t.py1 - t.py0, t.px1 - t.px0), []).append(i)
+    pieces = [None] * len(tiles)
+    for idx in groups.values():
+        crops = torch.stack([img[tiles[i].py0:tiles[i].py1, tiles[i].px0:tiles[i].px1] for i in idx])
+        outs = forward_u8(crops)
+        for j, i in enumerate(idx):
+            t = tiles[i]
+            oy, ox = (t.y0 - t.py0) * scale, (t.x0 - t.px0) * scale
+            pieces[i] = outs[j][oy:oy + (t.y1 - t.y0) * scale, ox:ox + (t.x1 - t.x0) * scale]
+    return pieces
+
+
+def upscale_tiled_batched(forward_u8, img: torch.Tensor, scale: int, tile_h: int, tile_w: int, halo: int) -> torch.Tensor:
+    """upscale_tiled with the tiles of equal crop shape batched (forward_u8 must accept uint8 [N,H,W,3])."""
+    h, w = img.shape[:2]
+    tiles = tile_grid(h, w, tile_h, tile_w, halo)
+    return stitch(tiles, upscale_tiles_batched(forward_u8, img, tiles, scale), h, w, scale)
+
+
 def upscale_tiled_sharded(forward_u8, img: torch.Tensor, scale: int, tile_h: int, tile_w: int, halo: int,
-                          rank: int, world: int, gather_to: int = 0, group=None):
+                          rank: int, world: int, gather_to: int = 0, group=None, batched: bool = False):
     """Each rank upscales tiles rank, rank+world, ...; the u8 pieces are gathered to `gather_to`,
-    which returns the stitched frame (other ranks return None).  One collective, at the end."""
+    which returns the stitched frame (other ranks return None).  One collective, at the end.
+    batched=True sends a rank's tiles of equal crop shape through forward_u8 together ([N,H,W,3])."""
     import torch.distributed as dist
     h, w = img.shape[:2]
     tiles = tile_grid(h, w, tile_h, tile_w, halo)
     mine = [i for i in range(len(tiles)) if i % world == rank]
-    pieces = {i: upscale_tile(forward_u8, img, tiles[i], scale) for i in mine}
+    if batched:
+        pieces = dict(zip(mine, upscale_tiles_batched(forward_u8, img, [tiles[i] for i in mine], scale)))
+    else:
+        pieces = {i: upscale_tile(forward_u8, img, tiles[i], scale) for i in mine}
     if world == 1:
         return stitch(tiles, [pieces[i] for i in range(len(tiles))], h, w, scale)
     # equal-size flat buffers so that one gather moves everything

@@ -188,6 +188,8 @@ def test_1080p_frame_whole_and_halo_tiled():
     assert torch.equal(whole, again)
     tiled = sharding.upscale_tiled(lambda t: eng.forward_u8(t), img, 4, 540, 480, 32)
     assert tuple(tiled.shape) == (4320, 7680, 3)
+    # tiles of equal crop shape sent through the lanes together: the same frame, bit for bit
+    assert torch.equal(sharding.upscale_tiled_batched(lambda t: eng.forward_u8(t), img, 4, 540, 480, 32), tiled)
     w_np, t_np = whole.cpu().numpy(), tiled.cpu().numpy()
     d = np.abs(w_np.astype(np.int32) - t_np.astype(np.int32))
     psnr = O.psnr_u8(w_np, t_np)

@@ -12,8 +12,9 @@ import torch.multiprocessing as mp
 from superresolution_amd import sharding, synth
 
 
-def fake_forward(img):  # u8 HWC -> u8 HWC x4 (nearest)
-    return img.repeat_interleave(4, dim=0).repeat_interleave(4, dim=1)
+def fake_forward(img):  # u8 HWC (or NHWC) -> u8 x4 (nearest)
+    d = img.dim() - 3
+    return img.repeat_interleave(4, dim=d).repeat_interleave(4, dim=d + 1)
 
 
 def test_shard_range_partitions_exactly():
@@ -41,6 +42,19 @@ def test_tile_grid_and_stitch():
     img = torch.from_numpy(synth.random_image(h, w, 1))
     out = sharding.upscale_tiled(fake_forward, img, 4, 32, 48, 10)
     assert torch.equal(out, fake_forward(img))
+    # tiles of equal crop shape stacked into one call: same frame, fewer calls
+    calls = []
+
+    def counting(x):
+        calls.append(tuple(x.shape))
+        return fake_forward(x)
+
+    assert torch.equal(sharding.upscale_tiled_batched(counting, img, 4, 32, 48, 10), fake_forward(img))
+    assert all(len(c) == 4 for c in calls) and sum(c[0] for c in calls) == len(tiles)
+    calls.clear()
+    big = torch.from_numpy(synth.random_image(128, 192, 2))          # 4 x 4 grid: 4 crop shapes (corner, two kinds of edge, interior) for 16 tiles
+    assert torch.equal(sharding.upscale_tiled_batched(counting, big, 4, 32, 48, 10), fake_forward(big))
+    assert len(calls) == 4 and all(c[0] == 4 for c in calls)
 
 
 def _free_port():
@@ -58,13 +72,14 @@ def _worker(rank, world, port, ret):
     try:
         img = torch.from_numpy(synth.random_image(70, 90, 3))
         out = sharding.upscale_tiled_sharded(fake_forward, img, 4, 32, 32, 6, rank, world)
+        out_b = sharding.upscale_tiled_sharded(fake_forward, img, 4, 32, 32, 6, rank, world, batched=True)
         frames = torch.from_numpy(synth.random_image(16, 20, 4, n=5))
         own, outs = sharding.upscale_frames_sharded(fake_forward, frames, rank, world)
         ok = all(torch.equal(o, fake_forward(frames[i])) for i, o in zip(own, outs))
         if rank == 0:
-            ok = ok and torch.equal(out, fake_forward(img))
+            ok = ok and torch.equal(out, fake_forward(img)) and torch.equal(out_b, out)
         else:
-            ok = ok and out is None
+            ok = ok and out is None and out_b is None
         ret[rank] = (bool(ok), list(own))
     finally:
         dist.destroy_process_group()
