@@ -84,6 +84,9 @@ EXPORTS = [
     "edsr_init", "edsr_release", "edsr_inference", "edsr_inference_ex",
     "rcan_init", "rcan_release", "rcan_inference", "rcan_inference_ex",
     "realesrgan_init", "realesrgan_release", "realesrgan_inference", "realesrgan_inference_ex",
+    "sr_init", "sr_release", "sr_inference", "sr_reserve", "sr_last_error",
+    "srmi_executor_create", "srmi_executor_destroy", "srmi_executor_run", "srmi_executor_input_size",
+    "srmi_executor_output_size",
 ]
 
 _lib = None

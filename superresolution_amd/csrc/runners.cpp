@@ -15,6 +15,7 @@
 #include "../../include/edsr.h"
 #include "../../include/rcan.h"
 #include "../../include/realesrgan.h"
+#include "../../include/sr.h"
 #include "common.h"
 
 
@@ -350,3 +351,75 @@ extern "C" int realesrgan_inference_ex(realesrgan_context_t* ctx, const unsigned
 
 SRMI_MEANSHIFT_RUNNER(edsr, SRMI_ARCH_EDSR, 256, 256)
 SRMI_MEANSHIFT_RUNNER(rcan, SRMI_ARCH_RCAN, 510, 339)
+
+// ---- generic runner (include/sr.h): any of the three networks, native input size ---------------------------
+extern "C" int sr_init(const char* model_path, sr_context_t* ctx) {
+    if (!model_path || !ctx) { fprintf(stderr, "[ERROR] Invalid parameters\n"); return -1; }
+    memset(ctx, 0, sizeof(*ctx));
+    int device = 0;
+    srmi_model_t* m = nullptr;
+    srmi_model_desc_t d;
+    if (srmi_pick_device(&device) || srmi_load_weight_file(model_path, 0, device, &m, &d)) {
+        log_error("sr_init");
+        return -1;
+    }
+    if (d.arch != SRMI_ARCH_RRDBNET && !d.with_meanshift) {
+        // a core EDSR / RCAN file: the runner subtracts and adds the dataset mean itself (edsr.cpp:36-37,116)
+        const float shift[3] = {0.4488f * 255.0f, 0.4371f * 255.0f, 0.4040f * 255.0f};
+        if (srmi_model_set_rgb_shift(m, shift)) {
+            srmi_model_destroy(m);
+            log_error("sr_init");
+            return -1;
+        }
+    }
+    ctx->executor = m;
+    ctx->arch = d.arch;
+    ctx->scale_factor = d.scale;
+    ctx->channels = 3;
+    ctx->initialized = 1;
+    return 0;
+}
+
+extern "C" int sr_release(sr_context_t* ctx) {
+    if (!ctx || !ctx->initialized) return 0;
+    srmi_model_destroy((srmi_model_t*)ctx->executor);
+    ctx->executor = nullptr;
+    ctx->initialized = 0;
+    return 0;
+}
+
+extern "C" int sr_reserve(sr_context_t* ctx, int input_width, int input_height) {
+    if (!ctx || !ctx->initialized) { fprintf(stderr, "[ERROR] Invalid parameters\n"); return -1; }
+    if (input_width <= 0 || input_height <= 0) { fprintf(stderr, "[ERROR] Invalid input size\n"); return -1; }
+    if (srmi_model_reserve_host((srmi_model_t*)ctx->executor, 1, input_height, input_width)) {
+        log_error("sr_reserve");
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int sr_inference(sr_context_t* ctx, const unsigned char* input_rgb, int input_width, int input_height,
+                            unsigned char** output_rgb, int* output_width, int* output_height) {
+    if (!ctx || !ctx->initialized || !input_rgb || !output_rgb) { fprintf(stderr, "[ERROR] Invalid parameters\n"); return -1; }
+    if (input_width <= 0 || input_height <= 0) { fprintf(stderr, "[ERROR] Invalid input size\n"); return -1; }
+    const size_t s = (size_t)ctx->scale_factor;
+    const size_t out_bytes = (size_t)input_width * s * (size_t)input_height * s * 3;
+    unsigned char* host = (unsigned char*)malloc(out_bytes);
+    if (!host) {
+        set_error("sr_inference: cannot allocate %zu bytes for the output image", out_bytes);
+        log_error("sr_inference");
+        return -1;
+    }
+    if (srmi_model_forward_u8_host((srmi_model_t*)ctx->executor, input_rgb, host, 1, input_height, input_width,
+                                   SRMI_ROUND_HALF_UP)) {
+        free(host);
+        log_error("sr_inference");
+        return -1;
+    }
+    *output_rgb = host;
+    if (output_width) *output_width = input_width * ctx->scale_factor;
+    if (output_height) *output_height = input_height * ctx->scale_factor;
+    return 0;
+}
+
+extern "C" const char* sr_last_error(void) { return srmi_last_error(); }

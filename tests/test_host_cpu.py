@@ -22,10 +22,10 @@ def test_library_exports_every_declared_symbol():
     # every function the headers declare is in EXPORTS
     import re
     declared = set()
-    for hname in ("srmi355.h", "edsr.h", "rcan.h", "realesrgan.h"):
+    for hname in ("srmi355.h", "edsr.h", "rcan.h", "realesrgan.h", "sr.h", "mi355_executor.h"):
         text = open(os.path.join(ROOT, "include", hname)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        declared |= set(re.findall(r"\b((?:srmi|edsr|rcan|realesrgan)_[a-z0-9_]+)\s*\(", text))
+        declared |= set(re.findall(r"\b((?:srmi|edsr|rcan|realesrgan|sr)_[a-z0-9_]+)\s*\(", text))
     assert declared <= set(_lib.EXPORTS), declared - set(_lib.EXPORTS)
     assert L.srmi_version().startswith(b"srmi355")
     assert L.srmi_device_count() >= 0

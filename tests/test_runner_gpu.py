@@ -122,6 +122,58 @@ def test_meanshift_runners(tmp_path, name, core):
     assert release(C.byref(ctx)) == 0  # uninitialised context -> 0 (edsr.cpp:185-187)
 
 
+class SrCtx(C.Structure):
+    _fields_ = [("executor", C.c_void_p), ("arch", C.c_int), ("scale_factor", C.c_int), ("channels", C.c_int),
+                ("initialized", C.c_int)]
+
+
+@pytest.mark.parametrize("arch", ["rrdbnet", "edsr", "edsr_core", "rcan"])
+def test_generic_runner_any_network_any_size(tmp_path, arch):
+    """include/sr.h: one init / inference / release for the three networks, native input size (no resize), the
+    per-network runner's pre/post-processing; checked against the oracle's runner pipeline at two odd sizes."""
+    L = _lib.lib()
+    L.sr_last_error.restype = C.c_char_p
+    from superresolution_amd import edsr_model
+    if arch == "rrdbnet":
+        meta, code, scale = dict(arch="rrdbnet", num_block=2, scale=2, seed=51, input="unit"), _lib.ARCH_RRDBNET, 2
+    elif arch.startswith("edsr"):
+        meta, code, scale = dict(arch="edsr", n_resblocks=2, n_feats=64, scale=3, seed=52, input="range"), _lib.ARCH_EDSR, 3
+    else:
+        meta, code, scale = dict(arch="rcan", n_resgroups=1, n_resblocks=2, scale=4, seed=53, input="range"), _lib.ARCH_RCAN, 4
+    model, sd = H.build_model(meta, "f16")
+    if arch == "edsr_core":
+        model = edsr_model.create_core_model_from_full(model, scale)
+    path = str(tmp_path / f"{arch}.srmi")
+    export.save_weights(model, path)
+    ctx = SrCtx()
+    assert L.sr_init(path.encode(), C.byref(ctx)) == 0
+    assert (ctx.arch, ctx.scale_factor, ctx.channels, ctx.initialized) == (code, scale, 3, 1)
+    assert L.sr_reserve(C.byref(ctx), 61, 45) == 0
+    for i, (h, w) in enumerate([(45, 61), (17, 130)]):
+        img = synth.smooth_image(h, w, 70 + i)
+        out, ow, oh = C.c_void_p(), C.c_int(), C.c_int()
+        assert L.sr_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), w, h, C.byref(out), C.byref(ow), C.byref(oh)) == 0
+        assert (ow.value, oh.value) == (w * scale, h * scale)
+        got = _take(out, h * scale, w * scale)
+        with torch.no_grad():
+            if arch == "rrdbnet":
+                ref = O.post_unit(H.oracle_forward(meta, sd, O.pre_unit(img)), O.ROUND_HALF_UP)[0]
+            else:
+                ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(img)), O.ROUND_HALF_UP)[0]
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() <= 1 and O.psnr_u8(got, ref) >= 50, (arch, h, w, int(d.max()))
+    img = synth.smooth_image(8, 8, 1)
+    out = C.c_void_p()
+    assert L.sr_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), 8, 8, C.byref(out), None, None) == 0  # NULL sizes allowed
+    libc.free(out)
+    assert L.sr_inference(C.byref(ctx), None, 8, 8, C.byref(out), None, None) == -1
+    assert L.sr_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), 0, 8, C.byref(out), None, None) == -1
+    assert L.sr_release(C.byref(ctx)) == 0 and ctx.initialized == 0
+    assert L.sr_release(C.byref(ctx)) == 0
+    assert L.sr_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), 8, 8, C.byref(out), None, None) == -1
+    assert L.sr_init(b"/nonexistent/file", C.byref(ctx)) == -1 and b"cannot open" in L.sr_last_error()
+
+
 def test_wrong_architecture_file_is_rejected(tmp_path):
     L = _lib.lib()
     model, _ = H.build_model(dict(arch="edsr", n_resblocks=1, n_feats=64, scale=4, seed=1, input="range"), "f16")
