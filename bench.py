@@ -237,6 +237,34 @@ def tiled_1080p_config(steps, device, tile_h=540, tile_w=480, halo=32, lanes=3):
     return rec
 
 
+def vendor_gemm_tflops(dtype, seconds=1.0):
+    """The vendor GEMM (torch.matmul -> hipBLASLt, 8192^3, uniform random operands) on this device, right after the
+    timed region: the dense rate the chip sustains at its power limit today, the practical ceiling that the conv
+    kernel's fraction of the nominal peak should be read against (devices of this pool differ by several per cent)."""
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16}.get(dtype)
+    if dt is None:
+        return None
+    n = 8192
+    a = (torch.rand(n, n, device="cuda") * 2 - 1).to(dt)
+    b = (torch.rand(n, n, device="cuda") * 2 - 1).to(dt)
+    c = torch.empty(n, n, device="cuda", dtype=dt)
+    for _ in range(5):
+        torch.matmul(a, b, out=c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:      # reach the steady power state first
+        for _ in range(20):
+            torch.matmul(a, b, out=c)
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(50):
+        torch.matmul(a, b, out=c)
+    ev1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n ** 3 / (ev0.elapsed_time(ev1) / 1e3 / 50) / 1e12
+
+
 def host_path(eng, h, w, batch, steps, rank):
     """The reference API's shape (host u8 image in, host u8 image out; realesrgan.cpp:217-257), PCIe transfers and
     host copies included: srmi_model_forward_u8_host on pageable numpy frames, wall clock."""
@@ -466,6 +494,14 @@ def main():
                                          "frac": round(flops_frame / serial / 1e12 / peak, 4),
                                          "avg_launch_us": round(serial / launches * 1e6, 3),
                                          "note": "one lane: launches run back to back, as under rocprofv3 --kernel-trace"}
+        if not args.no_side_configs and world == 1 and not args.tiles and not args.w8a8:
+            g = vendor_gemm_tflops(args.dtype)
+            if g:
+                rec["roofline"]["vendor_gemm"] = {
+                    "tflops": round(g, 1), "frac_of_peak": round(g / peak, 4),
+                    "conv_over_vendor_gemm": round(achieved / g, 4),
+                    "note": f"torch.matmul (hipBLASLt) 8192^3 {args.dtype}, random operands, same device, measured right "
+                            "after the timed region: both run on the socket's power cap (profiles/r02_power_trace.md)"}
         if not args.no_side_configs and world == 1 and args.model == "rrdbnet" and args.streams == 1 and not args.tiles:
             hp = host_path(eng, h, w, batch, max(2, args.steps // 4), rank)
             hp["frac_of_hbm_resident_rate"] = round(hp["value"] / rec["value"], 3)
