@@ -1,0 +1,210 @@
+// MFMA shape against sustained rate on a power-limited chip: the inner loop of the 3x3 convolution (every
+// operand fragment read from LDS with ds_read_b128, 0.89 fragment reads per 32x32x16 MFMA, three 4-wave
+// workgroups of 48 KiB per CU) with v_mfma_f32_32x32x16 against the same FLOPs and the same LDS bytes issued as
+// v_mfma_f32_16x16x32, f16 and bf16, on random operands.  No global traffic inside the loop.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_shape_bench.hip -o gpurun_out/mfma_shape_bench
+//   ./mfma_shape_bench [seconds per case]         -> one JSON line per case (TFLOP/s, in-kernel clock)
+//
+// One "stage pair" per wave = the work of two 16-channel stages of a 3-row x 32-pixel x 32-output wave tile:
+// 54 MFMAs 32x32x16 or 108 MFMAs 16x16x32 (the two-plane-stage form, K = 32), 48 fragments of 1 KiB either way.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x)                                                                        \
+    do {                                                                                \
+        hipError_t e_ = (x);                                                            \
+        if (e_ != hipSuccess) {                                                         \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));   \
+            exit(1);                                                                    \
+        }                                                                               \
+    } while (0)
+
+constexpr int kLds = 48 * 1024;
+
+template <bool BF>
+__device__ __forceinline__ void mma32(f32x16& c, const u32x4& a, const u32x4& b) {
+    if constexpr (BF)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ void mma16(f32x4& c, const u32x4& a, const u32x4& b) {
+    if constexpr (BF)
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// SHAPE 32: per horizontal tap and plane 3 weight fragments + 5 pixel-row fragments feed 9 MFMAs (3 rows x 3
+// vertical taps).  SHAPE 16: per horizontal tap 6 weight fragments (3 vertical taps x 2 halves of the 32 outputs,
+// K = 32 = both planes) + 10 pixel fragments (5 rows x 2 halves of the 32 pixels) feed 36 MFMAs.
+template <int SHAPE, bool BF>
+__global__ __launch_bounds__(256, 3) void loop_kernel(const uint4* __restrict__ src, float* __restrict__ sink, int pairs,
+                                                      unsigned long long* __restrict__ clk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < kLds / 16; i += 256) ((uint4*)smem)[i] = src[(blockIdx.x * (kLds / 16) + i) & 0xFFFFF];
+    __syncthreads();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const int frags = kLds / 1024;  // 48 fragments of 1 KiB in the workgroup's LDS
+    if constexpr (SHAPE == 32) {
+        f32x16 acc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+        for (int it = 0; it < pairs; ++it) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {      // the two planes of the pair, one after the other
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    u32x4 wf[3], pf[5];
+                    const int base = (it + half * 24 + dx * 8) % frags;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wf[k] = *(const u32x4*)(smem + ((base + k) % frags) * 1024 + lane * 16);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) pf[k] = *(const u32x4*)(smem + ((base + 3 + k) % frags) * 1024 + lane * 16);
+#pragma unroll
+                    for (int rho = 0; rho < 5; ++rho)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int r = rho - dy;
+                            if (r >= 0 && r < 3) mma32<BF>(acc[r], wf[dy], pf[rho]);
+                        }
+                }
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += acc[r][i];
+        if (s == 123.456f) sink[blockIdx.x * 256 + tid] = s;
+    } else {
+        f32x4 acc[3][2][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[r][a][b][i] = 0.f;
+        for (int it = 0; it < pairs; ++it) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                u32x4 wf[3][2], pf[5][2];
+                const int base = (it + dx * 16) % frags;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) wf[k >> 1][k & 1] = *(const u32x4*)(smem + ((base + k) % frags) * 1024 + lane * 16);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) pf[k >> 1][k & 1] = *(const u32x4*)(smem + ((base + 6 + k) % frags) * 1024 + lane * 16);
+#pragma unroll
+                for (int rho = 0; rho < 5; ++rho)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = rho - dy;
+                        if (r >= 0 && r < 3) {
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                                for (int b = 0; b < 2; ++b) mma16<BF>(acc[r][a][b], wf[dy][a], pf[rho][b]);
+                        }
+                    }
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s += acc[r][a][b][i];
+        if (s == 123.456f) sink[blockIdx.x * 256 + tid] = s;
+    }
+    if (clk && lane == 0) {
+        const size_t o = ((size_t)blockIdx.x * 4 + (tid >> 6)) * 2;
+        clk[o] = __builtin_amdgcn_s_memtime() - c0;
+        clk[o + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
+template <int SHAPE, bool BF>
+static void run_case(const char* name, const uint4* src, float* sink, unsigned long long* clk, double seconds) {
+    const int grid = 768, pairs = 4000;
+    auto k = loop_kernel<SHAPE, BF>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    // reach the steady power state first
+    double spent = 0;
+    while (spent < seconds) {
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 5; ++i) k<<<grid, 256, kLds>>>(src, sink, pairs, nullptr);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        spent += ms / 1e3;
+    }
+    CHECK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) k<<<grid, 256, kLds>>>(src, sink, pairs, i == reps - 1 ? clk : nullptr);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    // FLOPs: per wave and pair 54 MFMAs of 32x32x16 (or their equivalent) = 54 * 32768
+    const double flop = (double)reps * grid * 4 * pairs * 54.0 * 32768.0;
+    std::vector<unsigned long long> h((size_t)grid * 4 * 2);
+    CHECK(hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (size_t i = 0; i < h.size(); i += 2)
+        if (h[i + 1]) ghz.push_back((double)h[i] / (double)h[i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    printf("{\"case\": \"%s\", \"tflops\": %.1f, \"frac_of_2500\": %.3f, \"ms_per_launch\": %.3f, \"in_kernel_clock_ghz\": %.3f}\n",
+           name, flop / (ms / 1e3) / 1e12, flop / (ms / 1e3) / 2.5e15, ms / reps, ghz.empty() ? 0.0 : ghz[ghz.size() / 2]);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
+    const size_t n = 1 << 20;  // 16 MiB of random halves in [-1, 1)
+    std::vector<uint16_t> h(n * 8);
+    uint32_t s = 12345u;
+    for (auto& v : h) {
+        s = s * 1664525u + 1013904223u;
+        // sign, exponent 0x38..0x3b (f16: 0.5 .. 1, bf16 reads the same bits as small normal numbers), random mantissa
+        v = (uint16_t)(((s >> 16) & 0x8000u) | 0x3800u | ((s >> 8) & 0x03FFu));
+    }
+    uint4* src;
+    float* sink;
+    unsigned long long* clk;
+    CHECK(hipMalloc((void**)&src, n * 16));
+    CHECK(hipMalloc((void**)&sink, 768 * 256 * 4));
+    CHECK(hipMalloc((void**)&clk, 768 * 4 * 2 * 8));
+    CHECK(hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice));
+    for (int round = 0; round < 2; ++round) {
+        run_case<32, false>("f16 32x32x16", src, sink, clk, seconds);
+        run_case<16, false>("f16 16x16x32", src, sink, clk, seconds);
+        run_case<32, true>("bf16 32x32x16", src, sink, clk, seconds);
+        run_case<16, true>("bf16 16x16x32", src, sink, clk, seconds);
+    }
+    return 0;
+}
