@@ -6,12 +6,18 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/mfma_shape_bench.hip -o gpurun_out/mfma_shape_bench
 //   ./mfma_shape_bench [seconds per case]         -> one JSON line per case (TFLOP/s, in-kernel clock)
 //
+// Second part ("staging" cases, 32x32x16 f16 only): the same loop with the real kernel's global -> LDS staging added
+// step by step, to price its parts on the power cap: LDS-DMA pieces issued between the MFMAs (24 KiB per workgroup and
+// stage: 15 KiB of "pixels" from a buffer that is L2-resident, Infinity-Cache-resident or HBM-sized, 9 KiB of "weights"
+// that every workgroup shares), first free-running (no wait ever), then with the stage's s_waitcnt vmcnt(0) + s_barrier.
+//
 // One "stage pair" per wave = the work of two 16-channel stages of a 3-row x 32-pixel x 32-output wave tile:
 // 54 MFMAs 32x32x16 or 108 MFMAs 16x16x32 (the two-plane-stage form, K = 32), 48 fragments of 1 KiB either way.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -51,9 +57,16 @@ __device__ __forceinline__ void mma16(f32x4& c, const u32x4& a, const u32x4& b) 
 // SHAPE 32: per horizontal tap and plane 3 weight fragments + 5 pixel-row fragments feed 9 MFMAs (3 rows x 3
 // vertical taps).  SHAPE 16: per horizontal tap 6 weight fragments (3 vertical taps x 2 halves of the 32 outputs,
 // K = 32 = both planes) + 10 pixel fragments (5 rows x 2 halves of the 32 pixels) feed 36 MFMAs.
-template <int SHAPE, bool BF>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+
+// STAGING 0: none.  1: DMA pieces issued, never waited for.  2: + s_waitcnt vmcnt(0) and s_barrier per stage.
+// pix / pix_bytes: the buffer the pixel pieces stream through (each workgroup walks its own 15 KiB windows).
+template <int SHAPE, bool BF, int STAGING = 0>
 __global__ __launch_bounds__(256, 3) void loop_kernel(const uint4* __restrict__ src, float* __restrict__ sink, int pairs,
-                                                      unsigned long long* __restrict__ clk) {
+                                                      unsigned long long* __restrict__ clk, const char* pix = nullptr,
+                                                      unsigned long long pix_bytes = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < kLds / 16; i += 256) ((uint4*)smem)[i] = src[(blockIdx.x * (kLds / 16) + i) & 0xFFFFF];
@@ -66,11 +79,43 @@ __global__ __launch_bounds__(256, 3) void loop_kernel(const uint4* __restrict__ 
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned long long windows = STAGING ? pix_bytes / (16 * 1024) : 1;
         for (int it = 0; it < pairs; ++it) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {      // the two planes of the pair, one after the other
+                __amdgpu_buffer_rsrc_t ra, rb;
+                char* slot = smem + half * (24 * 1024);
+                if constexpr (STAGING) {
+                    if constexpr (STAGING == 2) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    const unsigned long long stage = (unsigned long long)it * 2 + half;
+                    const unsigned long long win = ((unsigned long long)blockIdx.x * 7919ull + stage) % windows;
+                    ra = make_rsrc(pix + win * (16 * 1024), 16 * 1024);              // this stage's pixel window
+                    rb = make_rsrc((const char*)src + (stage % 12) * (9 * 1024), 9 * 1024);  // weights: shared by all
+                }
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
+                    if constexpr (STAGING) {
+                        // two of the wave's six pieces per horizontal tap: pieces 0-3 of a wave are pixel pieces
+                        // (15 of them per workgroup), 4-5 weight pieces (9 per workgroup)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int q = dx * 2 + j;
+                            if (q < 4) {
+                                const int k = wave + 4 * q;
+                                if (k < 15)
+                                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(slot + k * 1024),
+                                                                             16, k * 1024 + lane * 16, 0, 0, 0);
+                            } else {
+                                const int k = wave + 4 * (q - 4);
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(slot + (15 + k) * 1024),
+                                                                         16, k * 1024 + lane * 16, 0, 0, 0);
+                            }
+                        }
+                    }
                     u32x4 wf[3], pf[5];
                     const int base = (it + half * 24 + dx * 8) % frags;
 #pragma unroll
@@ -144,10 +189,11 @@ __global__ __launch_bounds__(256, 3) void loop_kernel(const uint4* __restrict__ 
     }
 }
 
-template <int SHAPE, bool BF>
-static void run_case(const char* name, const uint4* src, float* sink, unsigned long long* clk, double seconds) {
+template <int SHAPE, bool BF, int STAGING = 0>
+static void run_case(const char* name, const uint4* src, float* sink, unsigned long long* clk, double seconds,
+                     const char* pix = nullptr, unsigned long long pix_bytes = 0) {
     const int grid = 768, pairs = 4000;
-    auto k = loop_kernel<SHAPE, BF>;
+    auto k = loop_kernel<SHAPE, BF, STAGING>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -156,7 +202,7 @@ static void run_case(const char* name, const uint4* src, float* sink, unsigned l
     double spent = 0;
     while (spent < seconds) {
         CHECK(hipEventRecord(e0));
-        for (int i = 0; i < 5; ++i) k<<<grid, 256, kLds>>>(src, sink, pairs, nullptr);
+        for (int i = 0; i < 5; ++i) k<<<grid, 256, kLds>>>(src, sink, pairs, nullptr, pix, pix_bytes);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -165,7 +211,7 @@ static void run_case(const char* name, const uint4* src, float* sink, unsigned l
     }
     CHECK(hipEventRecord(e0));
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) k<<<grid, 256, kLds>>>(src, sink, pairs, i == reps - 1 ? clk : nullptr);
+    for (int i = 0; i < reps; ++i) k<<<grid, 256, kLds>>>(src, sink, pairs, i == reps - 1 ? clk : nullptr, pix, pix_bytes);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -200,11 +246,26 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc((void**)&sink, 768 * 256 * 4));
     CHECK(hipMalloc((void**)&clk, 768 * 4 * 2 * 8));
     CHECK(hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice));
-    for (int round = 0; round < 2; ++round) {
+    const bool staging_only = argc > 2 && !strcmp(argv[2], "staging");
+    for (int round = 0; round < 2 && !staging_only; ++round) {
         run_case<32, false>("f16 32x32x16", src, sink, clk, seconds);
         run_case<16, false>("f16 16x16x32", src, sink, clk, seconds);
         run_case<32, true>("bf16 32x32x16", src, sink, clk, seconds);
         run_case<16, true>("bf16 16x16x32", src, sink, clk, seconds);
+    }
+    // staging: pixel windows streamed through 2 MiB (L2-resident), 128 MiB (Infinity Cache) and 2 GiB (HBM)
+    char* pix;
+    const unsigned long long big = 2ull << 30;
+    CHECK(hipMalloc((void**)&pix, big));
+    for (unsigned long long o = 0; o < big; o += n * 16) CHECK(hipMemcpy(pix + o, src, n * 16, hipMemcpyDeviceToDevice));
+    for (int round = 0; round < 2; ++round) {
+        run_case<32, false, 0>("f16 32x32x16 loop only", src, sink, clk, seconds);
+        run_case<32, false, 1>("f16 32x32x16 + DMA free-running, pixels from 2 MiB (L2)", src, sink, clk, seconds, pix, 2ull << 20);
+        run_case<32, false, 1>("f16 32x32x16 + DMA free-running, pixels from 128 MiB (Infinity Cache)", src, sink, clk, seconds, pix, 128ull << 20);
+        run_case<32, false, 1>("f16 32x32x16 + DMA free-running, pixels from 2 GiB (HBM)", src, sink, clk, seconds, pix, big);
+        run_case<32, false, 2>("f16 32x32x16 + DMA + wait and barrier per stage, pixels from 2 MiB (L2)", src, sink, clk, seconds, pix, 2ull << 20);
+        run_case<32, false, 2>("f16 32x32x16 + DMA + wait and barrier per stage, pixels from 128 MiB (Infinity Cache)", src, sink, clk, seconds, pix, 128ull << 20);
+        run_case<32, false, 2>("f16 32x32x16 + DMA + wait and barrier per stage, pixels from 2 GiB (HBM)", src, sink, clk, seconds, pix, big);
     }
     return 0;
 }
