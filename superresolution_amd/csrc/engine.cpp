@@ -500,6 +500,10 @@ static int run_rrdbnet(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int 
     if (up == 2) U2 = A.take(nf, hh, ww, T);
     U3 = A.take(nf, hh, ww, T);
     if (!ex) return 0;
+#ifdef SRMI_DIAG
+    // timing ablation (wrong results): both dense buffers are one, a lane touches 66 MB less
+    if (getenv("SRMI_ABL_ONE_DENSE")) D[1] = D[0];
+#endif
 
     // conv_first -> D0[0:nf] (conv input of the first RDB) and F (kept for the long skip);
     // F doubles as R of the first RRDB.
