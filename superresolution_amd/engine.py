@@ -171,6 +171,8 @@ class Engine:
             out = np.empty(shape, dtype=np.uint8)
         elif out.dtype != np.uint8 or out.shape != shape or not out.flags.c_contiguous:
             raise ValueError(f"out must be a C-contiguous uint8 array of shape {shape}")
+        if n == 0:
+            return out
         check(lib().srmi_model_forward_u8_host(self._h, a.ctypes.data, out.ctypes.data, n, h, w, round_mode),
               "srmi_model_forward_u8_host")
         return out
@@ -184,6 +186,8 @@ class Engine:
         shape = (n, 3, h * self.scale, w * self.scale)
         out = torch.empty(shape, dtype=torch.float32, device=self.device) if out is None else \
             self._check_out(out, shape, torch.float32)
+        if n == 0:      # an empty batch gives an empty result, as the reference modules do (nothing to launch)
+            return out
         check(lib().srmi_model_forward_f32(self._h, x.data_ptr(), out.data_ptr(), n, h, w, self._stream()),
               "srmi_model_forward_f32")
         return out
@@ -200,6 +204,8 @@ class Engine:
         shape = (n, h * self.scale, w * self.scale, 3)
         out = torch.empty(shape, dtype=torch.uint8, device=self.device) if out is None else \
             self._check_out(out, shape, torch.uint8)
+        if n == 0:
+            return out
         check(lib().srmi_model_forward_u8(self._h, img.data_ptr(), out.data_ptr(), n, h, w, round_mode,
                                           self._stream()), "srmi_model_forward_u8")
         return out[0] if squeeze else out

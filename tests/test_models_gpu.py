@@ -226,6 +226,24 @@ def test_edge_inputs_constant_frames_and_tiny_sizes(arch):
         assert diff.max() <= 1, (arch, img.shape, int(diff.max()))
 
 
+def test_empty_batch_gives_an_empty_result():
+    """torch's conv2d / interpolate accept a batch of zero images, so the reference modules return an empty tensor
+    of the output shape; so do the f32, u8 and host-buffer paths here (nothing is launched)."""
+    meta = dict(arch="rrdbnet", num_block=1, scale=4, seed=3, input="unit")
+    model, sd = H.build_model(meta, "f16")
+    with torch.no_grad():
+        ref = H.oracle_forward(meta, sd, torch.zeros(0, 3, 9, 11))
+    assert tuple(ref.shape) == (0, 3, 36, 44)
+    y = model(torch.zeros(0, 3, 9, 11))
+    assert tuple(y.shape) == (0, 3, 36, 44) and y.dtype == torch.float32
+    eng = model.engine()
+    assert tuple(eng.forward_u8(torch.zeros(0, 9, 11, 3, dtype=torch.uint8).cuda()).shape) == (0, 36, 44, 3)
+    assert eng.forward_u8_host(np.zeros((0, 9, 11, 3), np.uint8)).shape == (0, 36, 44, 3)
+    # zero-sized frames are an error in the reference (conv2d rejects them) and here
+    with pytest.raises(Exception):
+        model(torch.zeros(1, 3, 0, 11))
+
+
 def test_halo_tiling_is_exact_when_halo_covers_the_receptive_field():
     """Tiles (+halo) of a frame upscaled independently and stitched == the whole frame upscaled,
     bit for bit, once the halo covers the receptive field (1 RRDB: 15 convs + conv_body + tail)."""
