@@ -250,6 +250,8 @@ static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
     cw.cout_tile = (cw.cout <= 32 || cw.cout % 64 || m->d.arch == SRMI_ARCH_RRDBNET) ? 32 : 64;
 #ifdef SRMI_DIAG  // diagnostic builds only: the shipped library takes no tiling from the environment
     if (getenv("SRMI_COUT_TILE")) cw.cout_tile = atoi(getenv("SRMI_COUT_TILE")) == 32 || cw.cout <= 32 ? 32 : 64;
+    // 64-wide tiles for RRDBNet's convs outside the dense blocks only (conv_body, the upsampling and HR convs)
+    if (getenv("SRMI_COUT_TILE_OUTER") && name.find(".rdb") == std::string::npos && cw.cout % 64 == 0) cw.cout_tile = 64;
 #endif
     cw.ps_r = ps_r;
     std::vector<float> rounded;
