@@ -5,7 +5,7 @@
 Starts the command as a child process and, every 50 ms until it exits, reads what the amdgpu driver
 publishes for the first GPU under /sys/class/drm/card*/device: hwmon power (power1_average or
 power1_input, microwatts), the power cap (power1_cap), the shader clock (freq1_input, Hz), the
-memory clock (freq2_input), the junction temperature and gpu_busy_percent; the shader clock also
+memory clock (freq2_input), the junction temperature, gpu_busy_percent and mem_busy_percent; the shader clock also
 from `rocm-smi --showclocks` every few hundred milliseconds (hwmon has no clock file on every driver).  One JSON object per
 sample goes to OUT.jsonl, and a summary (idle level, level while the GPU was busy, cap) is printed
 at the end.  Reading these files needs no privileges and touches no GPU state.
@@ -52,6 +52,7 @@ def sources(base):
         "mclk_Hz": _first([hw + "/freq2_input"]),
         "temp_mC": _first([hw + "/temp2_input", hw + "/temp1_input"]),
         "busy_pct": _first([base + "/gpu_busy_percent"]),
+        "mem_busy_pct": _first([base + "/mem_busy_percent"]),
     }
 
 
@@ -131,6 +132,7 @@ def main():
         "idle_power_W": stat(idle, "power_uW", 1e-6), "busy_power_W": stat(busy, "power_uW", 1e-6),
         "idle_sclk_MHz": stat(idle, "sclk_Hz", 1e-6), "busy_sclk_MHz": stat(busy, "sclk_Hz", 1e-6),
         "busy_mclk_MHz": stat(busy, "mclk_Hz", 1e-6), "busy_temp_C": stat(busy, "temp_mC", 1e-3),
+        "busy_mem_busy_pct": stat(busy, "mem_busy_pct", 1),
         "rocm_smi_sclk_MHz_while_busy": sorted(v for t, v in sclk if v >= 500),
         "command": " ".join(cmd), "child_rc": child.returncode,
     }
