@@ -226,6 +226,40 @@ def test_edge_inputs_constant_frames_and_tiny_sizes(arch):
         assert diff.max() <= 1, (arch, img.shape, int(diff.max()))
 
 
+def test_one_model_driven_from_two_threads_on_two_streams():
+    """Calls on one model share its workspace: the library orders them (a mutex around the enqueue, an event between
+    consecutive calls whatever stream they run on), so two threads with a stream each get the results a single
+    thread gets."""
+    import threading
+    meta = dict(arch="rcan", n_resgroups=1, n_resblocks=2, scale=4, seed=8, input="range")   # RCAN: shared sums / scale too
+    model, _ = H.build_model(meta, "f16")
+    eng = model.engine()
+    imgs = [torch.from_numpy(synth.random_image(37, 52, 80 + i, n=2)).cuda() for i in range(2)]
+    want = [eng.forward_u8(x).clone() for x in imgs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(8):
+                    got = eng.forward_u8(imgs[i])
+                    st.synchronize()
+                    if not torch.equal(got, want[i]):
+                        errors.append(f"thread {i}: result differs")
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_empty_batch_gives_an_empty_result():
     """torch's conv2d / interpolate accept a batch of zero images, so the reference modules return an empty tensor
     of the output shape; so do the f32, u8 and host-buffer paths here (nothing is launched)."""
