@@ -2,6 +2,7 @@
  * free -> release) from plain C against include/realesrgan.h, edsr.h and rcan.h, so the context structs are
  * the headers' own and not a re-typed copy.
  *   runner_demo realesrgan|edsr|rcan model.srmi in.u8 W H out.u8          one inference
+ *   runner_demo sr model.srmi in.u8 W H out.u8                             the generic runner of include/sr.h (any network, native size)
  *   runner_demo threads modelA.srmi modelB.srmi in.u8 W H outA.u8 outB.u8  two Real-ESRGAN contexts, one per
  *                                                                           thread, three inferences each at once
  */
@@ -13,6 +14,7 @@
 #include "edsr.h"
 #include "rcan.h"
 #include "realesrgan.h"
+#include "sr.h"
 
 static unsigned char* read_file(const char* path, size_t n) {
     unsigned char* p = (unsigned char*)malloc(n);
@@ -75,7 +77,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (argc != 7) {
-        fprintf(stderr, "usage: %s realesrgan|edsr|rcan model.srmi in.u8 W H out.u8\n", argv[0]);
+        fprintf(stderr, "usage: %s realesrgan|edsr|rcan|sr model.srmi in.u8 W H out.u8\n", argv[0]);
         return 2;
     }
     const int w = atoi(argv[4]), h = atoi(argv[5]);
@@ -93,6 +95,17 @@ int main(int argc, char** argv) {
         write_file(argv[6], out, (size_t)ow * oh * 3);
         free(out);
         if (realesrgan_release(&ctx) != 0 || ctx.initialized) return 1;
+    } else if (!strcmp(argv[1], "sr")) {
+        sr_context_t ctx;
+        memset(&ctx, 0, sizeof(ctx));
+        if (sr_release(&ctx) != 0 || sr_inference(&ctx, img, w, h, &out, &ow, &oh) != -1) return 1;
+        if (sr_init(argv[2], &ctx) != 0) { fprintf(stderr, "%s\n", sr_last_error()); return 1; }
+        if (sr_reserve(&ctx, w, h) != 0) return 1;
+        if (sr_inference(&ctx, img, w, h, &out, &ow, &oh) != 0) return 1;
+        if (ow != w * ctx.scale_factor || oh != h * ctx.scale_factor || ctx.channels != 3) return 1;
+        write_file(argv[6], out, (size_t)ow * oh * 3);
+        free(out);
+        if (sr_release(&ctx) != 0 || ctx.initialized) return 1;
     } else if (!strcmp(argv[1], "edsr")) {
         edsr_context_t ctx;
         memset(&ctx, 0, sizeof(ctx));

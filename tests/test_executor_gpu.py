@@ -97,6 +97,19 @@ def test_runner_api_from_c_and_two_contexts_on_two_threads(tmp_path):
     assert np.array_equal(np.fromfile(ob, dtype=np.uint8).reshape(1356, 2040, 3), wants[1])
 
 
+def test_generic_runner_from_c(tmp_path):
+    """include/sr.h compiled as C11 and driven from C: an RCAN x2 file on a frame of its own size."""
+    meta = dict(arch="rcan", n_resgroups=1, n_resblocks=1, scale=2, seed=74, input="range")
+    model, _ = H.build_model(meta, "f16")
+    wpath, ipath, opath = (str(tmp_path / f) for f in ("rcan_x2.srmi", "in.u8", "out.u8"))
+    export.save_weights(model, wpath)
+    img = synth.smooth_image(45, 70, 10)
+    img.tofile(ipath)
+    assert _run([_program("runner_demo"), "sr", wpath, ipath, "70", "45", opath]).startswith("ok 140x90")
+    got = np.fromfile(opath, dtype=np.uint8).reshape(90, 140, 3)
+    assert np.array_equal(got, model.forward_u8(img, _lib.ROUND_HALF_UP).numpy())
+
+
 def test_edsr_runner_from_c(tmp_path):
     meta = dict(arch="edsr", n_resblocks=1, n_feats=64, scale=4, seed=73, input="range")
     model, sd = H.build_model(meta, "f16")
