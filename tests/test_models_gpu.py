@@ -226,6 +226,42 @@ def test_edge_inputs_constant_frames_and_tiny_sizes(arch):
         assert diff.max() <= 1, (arch, img.shape, int(diff.max()))
 
 
+@pytest.mark.parametrize("arch", ["rrdbnet", "edsr", "rcan"])
+def test_outputs_stay_inside_their_buffers(arch):
+    """Out-of-bounds canaries: the u8 and f32 results are written into the middle of a larger buffer filled with a
+    pattern; after forwards at sizes that are not multiples of the 12 x 32 tile (and of the x2 / x3 / x4 shuffles)
+    every byte outside the result still holds the pattern, and the result equals the one written to a buffer of its own."""
+    meta = _u8_case(arch)
+    if arch == "rrdbnet":
+        meta = dict(meta, num_block=1)
+    elif arch == "edsr":
+        meta = dict(meta, n_resblocks=2, n_feats=64, scale=3)
+    else:
+        meta = dict(meta, n_resgroups=1, n_resblocks=2, scale=2)
+    model, _ = H.build_model(meta, "f16")
+    eng = model.engine()
+    s = eng.scale
+    guard = 1 << 16
+    for n, h, w in ((1, 13, 33), (2, 37, 51), (1, 1, 65)):
+        img = torch.from_numpy(synth.random_image(h, w, 90 + h, n=n)).cuda()
+        want = eng.forward_u8(img)
+        size = n * h * s * w * s * 3
+        big = torch.full((size + 2 * guard,), 0xA5, dtype=torch.uint8, device="cuda")
+        got = eng.forward_u8(img, out=big[guard:guard + size].view(n, h * s, w * s, 3))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert bool((big[:guard] == 0xA5).all()) and bool((big[guard + size:] == 0xA5).all()), (arch, n, h, w)
+        x = torch.from_numpy(synth.random_image(h, w, 91 + h, n=n)).permute(0, 3, 1, 2).float().cuda()
+        if arch == "rrdbnet":
+            x = x / 255.0
+        wantf = eng.forward_f32(x)
+        bigf = torch.full((size + 2 * guard,), -12345.0, dtype=torch.float32, device="cuda")
+        gotf = eng.forward_f32(x, out=bigf[guard:guard + size].view(n, 3, h * s, w * s))
+        torch.cuda.synchronize()
+        assert torch.equal(gotf, wantf)
+        assert bool((bigf[:guard] == -12345.0).all()) and bool((bigf[guard + size:] == -12345.0).all()), (arch, n, h, w)
+
+
 def test_one_model_driven_from_two_threads_on_two_streams():
     """Calls on one model share its workspace: the library orders them (a mutex around the enqueue, an event between
     consecutive calls whatever stream they run on), so two threads with a stream each get the results a single

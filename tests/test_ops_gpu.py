@@ -373,3 +373,28 @@ def test_attention_finished_inside_the_conv(dt, name, tol, c, mb):
     assert float((one.cpu() - ref).abs().max()) <= (1e-5 if dt == _lib.F32 else 2e-4)
     _, again = ops.conv3x3(xp, pc, rows_per_wave=mb, attention=(w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy()))
     assert torch.equal(again.cpu(), one.cpu())
+
+
+@pytest.mark.parametrize("dt,name,tol", DTYPES)
+def test_conv_writes_only_its_channel_slice(dt, name, tol):
+    """Out-of-bounds canary for the dense-block concat: a 32-output conv stores into channels [32, 64) of a wider
+    plane buffer filled with a pattern; at sizes that are not multiples of the tile every other plane, and a guard
+    band behind the buffer's last image, keep the pattern bit for bit."""
+    for n, h, w in ((1, 13, 33), (2, 25, 65)):
+        x = q(rnd("x", (n, 64, h, w), 1), dt)
+        wt = q(rnd("w", (32, 64, 3, 3), 2, 0.1), dt)
+        b = rnd("b", (32,), 3)
+        pc = ops.PackedConv(wt.numpy(), b.numpy(), dt)
+        out = ops.Planes(n + 1, 96, h, w, dt)          # one spare image behind the last one as the guard band
+        out.buf.fill_(3.0)
+        out.n = n
+        ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, act=_lib.ACT_LRELU, out=out, out_c0=32)
+        torch.cuda.synchronize()
+        cpb = ops.cpb(dt)
+        lo, hi = 32 // cpb, 64 // cpb
+        buf = out.buf.float()
+        assert bool((buf[:n, :lo] == 3.0).all()) and bool((buf[:n, hi:] == 3.0).all()) and bool((buf[n] == 3.0).all()), \
+            (name, n, h, w)
+        out.n = n + 1
+        got = out.to_nchw()[:n, 32:64].cpu()
+        assert_close(got, F.leaky_relu(F.conv2d(x, wt, b, padding=1), 0.2), tol, f"slice conv {name}")
