@@ -237,3 +237,17 @@ def test_demo_cli_usage_and_family_heuristic(capsys):
     assert demo.family_from_name("/x/EDSR_x4.srmi") == "edsr"
     assert demo.family_from_name("RCAN_BIX4.srmi") == "rcan"
     assert demo.family_from_name("RealESRGAN_x4plus.srmi") == "realesrgan"
+
+
+def test_weight_packing_under_host_sanitizers():
+    """csrc/pack.cpp built with AddressSanitizer and UBSan (host code only, tests/cpp/pack_sanitize.cpp): every
+    (dtype, cout, cin, tile, shuffle) combination the networks use packs into exactly-sized buffers without a report
+    and writes every byte of the image."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "pack_sanitize")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "bin/pack_sanitize"], check=True,
+                       capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
