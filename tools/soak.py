@@ -1,14 +1,25 @@
 """Repeats the bench step many times and checks that every repetition reproduces the first output bit for bit
-(catches races between the engine's stream lanes and workspace reuse)."""
+(catches races between the engine's stream lanes and workspace reuse, and in RCAN between the workgroups that
+add to the pooling sums and the one that finishes the attention).
+
+    python tools/soak.py [repetitions] [rrdbnet | rcan | rcan_f32trunk | edsr]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from superresolution_amd import RRDBNet, _lib, synth
+from superresolution_amd import EDSR, RCAN, RRDBNet, _lib, synth
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-m = RRDBNet(compute_dtype="f16", trunk_f32=False)
-m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.rrdbnet_state_dict(seed=0).items()}, strict=True)
+which = sys.argv[2] if len(sys.argv) > 2 else "rrdbnet"
+h, w = 339, 510
+if which == "rrdbnet":
+    m, sd = RRDBNet(compute_dtype="f16", trunk_f32=False), synth.rrdbnet_state_dict(seed=0)
+elif which.startswith("rcan"):
+    m, sd = RCAN(scale=4, compute_dtype="f16", trunk_f32=which == "rcan_f32trunk"), synth.rcan_state_dict(seed=0)
+else:
+    m, sd = EDSR(compute_dtype="f16", trunk_f32=False), synth.edsr_state_dict(seed=0)
+    h, w = 256, 256
+m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
 eng = m.engine()
-imgs = torch.from_numpy(synth.random_image(339, 510, 1, n=12)).cuda()
+imgs = torch.from_numpy(synth.random_image(h, w, 1, n=12)).cuda()
 ref = eng.forward_u8(imgs, _lib.ROUND_HALF_UP).clone()
 eng.set_lanes(1)
 one = eng.forward_u8(imgs, _lib.ROUND_HALF_UP)
