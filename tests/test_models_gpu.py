@@ -226,6 +226,40 @@ def test_edge_inputs_constant_frames_and_tiny_sizes(arch):
         assert diff.max() <= 1, (arch, img.shape, int(diff.max()))
 
 
+@pytest.mark.parametrize("shape", ["heavy_tailed", "sparse"])
+def test_half_precision_bound_on_other_weight_distributions(shape):
+    """The f16 margins elsewhere in this file are measured on uniformly distributed weights.  No real checkpoint is
+    available, so this is the next best thing: the same full-depth RRDBNet with the dense-block weights reshaped to a
+    heavy-tailed distribution (sign(w) |w|^3, a few weights carry most of the energy, as trained convolutions do) and to
+    a sparse one (four of five weights zero), both rescaled to the original RMS per tensor.  The bound is the same:
+    u8 diff <= 1 LSB and PSNR >= 50 dB against the fp32 oracle, with the two-precision dense blocks on and off."""
+    from superresolution_amd import RRDBNet
+    meta = dict(arch="rrdbnet", num_block=23, scale=4, seed=61, input="unit")
+    sd = H.state_dict_for(meta)
+    for k in list(sd):
+        if ".rdb" in k and k.endswith(".weight"):
+            w = sd[k].astype(np.float64)
+            rms = np.sqrt(np.mean(w * w))
+            if shape == "heavy_tailed":
+                v = np.sign(w) * np.abs(w / np.abs(w).max()) ** 3
+            else:
+                keep = synth.hash_uniform(k + ".mask", w.shape, 5) > 0.3      # uniform in [-0.5, 0.5): one in five kept
+                v = np.where(keep, w, 0.0)
+            sd[k] = (v * (rms / max(np.sqrt(np.mean(v * v)), 1e-30))).astype(np.float32)
+    img = synth.smooth_image(40, 56, 13)
+    with torch.no_grad():
+        ref = O.post_unit(H.oracle_forward(meta, sd, O.pre_unit(img)), O.ROUND_HALF_UP)[0]
+    assert ref.min() < 8 and ref.max() > 247 and 40 < ref.mean() < 215      # the frame still uses the whole range
+    for round8 in (True, False):
+        model = RRDBNet(num_block=23, scale=4, compute_dtype="f16", growth_round8=round8)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        got = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        psnr = O.psnr_u8(got, ref)
+        print(f"{shape} weights, two-precision dense blocks {round8}: max u8 diff {d.max()}, PSNR {psnr:.1f} dB")
+        assert d.max() <= 1 and psnr >= 50.0, (shape, round8, int(d.max()), psnr)
+
+
 @pytest.mark.parametrize("arch", ["rrdbnet", "edsr", "rcan"])
 def test_outputs_stay_inside_their_buffers(arch):
     """Out-of-bounds canaries: the u8 and f32 results are written into the middle of a larger buffer filled with a
