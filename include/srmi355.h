@@ -315,7 +315,9 @@ int srmi_model_reserve_host(srmi_model_t* m, int n, int h, int w);
  * allocation.  Inputs whose workspace exceeds the array (e.g. RRDBNet x4 beyond about 100x100 pixels
  * per image) fail with a message naming both sizes.  All models on one GPU share that GPU's array:
  * calls that overlap in time on one GPU (different streams or threads) race; calls on one stream, or
- * ordered by events, are safe.  Nothing in the array has to start at zero.
+ * ordered by events, are safe.  The array keeps the previous call's contents: the one region that must
+ * start at zero (RCAN's channel sums and arrival counters) is cleared on hip_stream at the start of
+ * every call, everything else is written before it is read.
  */
 int srmi_model_forward_u8_noalloc(srmi_model_t* m, const uint8_t* in, uint8_t* out, int n, int h, int w,
                                   int round_mode, void* hip_stream);
