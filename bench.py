@@ -325,6 +325,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier and the max-over-ranks reduce (gloo: rehearsal of the "
                          "multi-rank path on a box with fewer GPUs than ranks; ranks then share devices)")
+    ap.add_argument("--dist-always", action="store_true",
+                    help="initialise the process group even for one rank: runs the RCCL barrier and max-reduce of the "
+                         "multi-GPU path on a one-GPU box (launch under torch.distributed.run --nproc-per-node 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -339,12 +342,24 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_always:
         import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        # RCCL prints a version banner on the process's stdout when it creates its communicator; stdout carries
+        # the one JSON line, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     # workload: Real-ESRGAN x4plus on 510x339 frames is the headline configuration; the others are selectable
     defaults = {"rrdbnet": (339, 510, 12), "rcan": (339, 510, 12), "edsr": (256, 256, 36)}
@@ -386,7 +401,8 @@ def main():
         if args.tiles:
             from superresolution_amd import sharding
             return sharding.upscale_tiled_sharded(lambda t: eng.forward_u8(t, _lib.ROUND_HALF_UP), imgs[0], scale,
-                                                  540, 480, args.tiles, rank, world, batched=True)
+                                                  540, 480, args.tiles, rank, world, batched=True,
+                                                  always_gather=dist is not None)
         if streams is None:
             eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
             return

@@ -99,10 +99,13 @@ def upscale_tiled_batched(forward_u8, img: torch.Tensor, scale: int, tile_h: int
 
 
 def upscale_tiled_sharded(forward_u8, img: torch.Tensor, scale: int, tile_h: int, tile_w: int, halo: int,
-                          rank: int, world: int, gather_to: int = 0, group=None, batched: bool = False):
+                          rank: int, world: int, gather_to: int = 0, group=None, batched: bool = False,
+                          always_gather: bool = False):
     """Each rank upscales tiles rank, rank+world, ...; the u8 pieces are gathered to `gather_to`,
     which returns the stitched frame (other ranks return None).  One collective, at the end.
-    batched=True sends a rank's tiles of equal crop shape through forward_u8 together ([N,H,W,3])."""
+    batched=True sends a rank's tiles of equal crop shape through forward_u8 together ([N,H,W,3]).
+    always_gather=True runs the collective for a single rank too (needs an initialised process group): the
+    way to execute the RCCL gather of device buffers on a one-GPU box."""
     import torch.distributed as dist
     h, w = img.shape[:2]
     tiles = tile_grid(h, w, tile_h, tile_w, halo)
@@ -111,7 +114,7 @@ def upscale_tiled_sharded(forward_u8, img: torch.Tensor, scale: int, tile_h: int
         pieces = dict(zip(mine, upscale_tiles_batched(forward_u8, img, [tiles[i] for i in mine], scale)))
     else:
         pieces = {i: upscale_tile(forward_u8, img, tiles[i], scale) for i in mine}
-    if world == 1:
+    if world == 1 and not always_gather:
         return stitch(tiles, [pieces[i] for i in range(len(tiles))], h, w, scale)
     # equal-size flat buffers so that one gather moves everything
     per_rank = (len(tiles) + world - 1) // world
