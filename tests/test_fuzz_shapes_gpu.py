@@ -1,0 +1,18 @@
+"""Random image sizes around the conv kernel's tile boundaries (tools/fuzz_shapes.py): small networks of the three
+architectures, f32 engine against the oracle at the f32 bound and f16 engine at <= 1 LSB / >= 50 dB, 90 cases."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_shapes_against_the_oracle():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shapes.py"), "90", "3"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout[-3000:], r.stderr[-1500:])
+    assert r.returncode == 0
+    assert "90 cases, seed 3, 0 failed" in r.stdout

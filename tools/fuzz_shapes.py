@@ -1,0 +1,88 @@
+"""Shape fuzzer: small networks of the three architectures at image sizes drawn around the kernel's tile
+boundaries (rows: multiples of 8 / 12, columns: multiples of 32, each -1 / 0 / +1, plus random sizes and
+batches), f32 engine against the CPU oracle at the f32 bound, f16 engine at <= 1 LSB / >= 50 dB on the u8
+output.  Prints one line per failing case and a summary; exit status 1 if anything failed.
+
+    python tools/fuzz_shapes.py [cases] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from superresolution_amd import _lib, synth  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+ARCHS = [
+    dict(arch="rrdbnet", num_block=1, scale=4, input="unit"),
+    dict(arch="rrdbnet", num_block=1, scale=2, input="unit"),
+    dict(arch="edsr", n_resblocks=2, n_feats=64, scale=4, input="raw"),
+    dict(arch="edsr", n_resblocks=1, n_feats=64, scale=3, input="raw"),
+    dict(arch="rcan", scale=4, n_resgroups=1, n_resblocks=2, input="raw"),
+    dict(arch="rcan", scale=2, n_resgroups=2, n_resblocks=1, input="raw"),
+]
+
+
+def sizes(rng, count):
+    edge_h = sorted({max(1, m + d) for m in (8, 12, 16, 24, 36, 48) for d in (-1, 0, 1)})
+    edge_w = sorted({max(1, m + d) for m in (32, 64, 96) for d in (-1, 0, 1)})
+    out = []
+    for _ in range(count):
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            out.append((int(rng.choice(edge_h)), int(rng.choice(edge_w))))
+        elif kind == 1:
+            out.append((int(rng.integers(1, 60)), int(rng.choice(edge_w))))
+        else:
+            out.append((int(rng.integers(1, 60)), int(rng.integers(1, 110))))
+    return out
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    bad = 0
+    worst32, worst_lsb, worst_db = 0.0, 0.0, 99.0
+    t0 = time.time()
+    engines = {}
+    for i, (h, w) in enumerate(sizes(rng, cases)):
+        meta = dict(ARCHS[i % len(ARCHS)], seed=200 + i % len(ARCHS), h=h, w=w, n=int(rng.integers(1, 4)))
+        key = i % len(ARCHS)
+        if key not in engines:
+            m32, sd = H.build_model(meta, "f32")
+            m16, _ = H.build_model(meta, "f16")
+            engines[key] = (m32, m16, {k: torch.from_numpy(v) for k, v in sd.items()})
+        m32, m16, sd = engines[key]
+        x = H.input_for(meta)
+        want = H.oracle_forward(meta, sd, x)
+        got = m32(x.cuda()).cpu()
+        err = float((got - want).abs().max())
+        ok32 = got.shape == want.shape and err <= H.f32_tol(meta)
+        # u8 path of the f16 engine against the oracle's u8 result (half-up rounding)
+        img = synth.random_image(h, w, meta["seed"], n=meta["n"])
+        scale = 255.0 if meta["input"] == "unit" else 1.0
+        want_u8 = torch.floor(want.clamp(0, 1 if meta["input"] == "unit" else 255) * scale + 0.5).permute(0, 2, 3, 1)
+        got_u8 = m16.engine().forward_u8(torch.from_numpy(img).cuda(), _lib.ROUND_HALF_UP).cpu().float()
+        d = (got_u8 - want_u8).abs()
+        mse = float((d ** 2).mean())
+        psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+        ok16 = got_u8.shape == want_u8.shape and float(d.max()) <= 1 and psnr >= 50.0
+        worst32 = max(worst32, err / H.f32_tol(meta))
+        worst_lsb, worst_db = max(worst_lsb, float(d.max())), min(worst_db, psnr)
+        if not (ok32 and ok16):
+            bad += 1
+            print(f"FAIL {meta}: f32 max-abs {err:.3g} (bound {H.f32_tol(meta)}), f16 max u8 diff {float(d.max())}, {psnr:.1f} dB",
+                  flush=True)
+        if (i + 1) % 10 == 0:
+            print(f"{i + 1}/{cases} cases, {bad} failed, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz_shapes: {cases} cases, seed {seed}, {bad} failed; worst f32 error {worst32:.3f} of its bound, "
+          f"worst f16 result {worst_lsb:.0f} LSB / {worst_db:.1f} dB")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
