@@ -1,9 +1,12 @@
 """Shape fuzzer: small networks of the three architectures at image sizes drawn around the kernel's tile
 boundaries (rows: multiples of 8 / 12, columns: multiples of 32, each -1 / 0 / +1, plus random sizes and
 batches), f32 engine against the CPU oracle at the f32 bound, f16 engine at <= 1 LSB / >= 50 dB on the u8
-output.  Prints one line per failing case and a summary; exit status 1 if anything failed.
+output.  Then, with a third argument, that many standalone convolutions (random channel counts, tile height, cout tile,
+activation, residual, dtype, image size and batch) against torch's fp32 conv2d on operands rounded to the compute
+type, and as many bilinear u8 resizes at random sizes against the oracle (bit-exact).
+Prints one line per failing case and a summary; exit status 1 if anything failed.
 
-    python tools/fuzz_shapes.py [cases] [seed]
+    python tools/fuzz_shapes.py [cases] [seed] [op_cases]
 """
 import os
 import sys
@@ -13,8 +16,56 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from superresolution_amd import _lib, synth  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import sr_oracle as O  # noqa: E402
+from superresolution_amd import _lib, ops, synth  # noqa: E402
 from tests import helpers as H  # noqa: E402
+
+TORCH_DT = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}
+OP_TOL = {_lib.F32: 2e-5, _lib.F16: 2.0 ** -10, _lib.BF16: 2.0 ** -7}
+
+
+def fuzz_ops(rng, cases):
+    """Standalone convolutions and resizes; returns the number of failures."""
+    bad = 0
+    for i in range(cases):
+        dt = [_lib.F32, _lib.F16, _lib.BF16][int(rng.integers(0, 3))]
+        cin = 32 * int(rng.integers(1, 7))
+        cout = 32 * int(rng.integers(1, 5))
+        cout_tile = 64 if (cout % 64 == 0 and rng.integers(0, 2)) else 32
+        mb = int(rng.choice([2, 3] if cout_tile == 64 else [2, 3, 4]))
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 50)), int(rng.integers(1, 100))
+        act = [_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LRELU][int(rng.integers(0, 3))]
+        rq = lambda key, shape, amp=1.0: (torch.from_numpy(synth.hash_uniform(key, shape, 1000 + i)) * amp).to(TORCH_DT[dt]).float()
+        x, wt = rq("x", (n, cin, h, w)), rq("w", (cout, cin, 3, 3), 0.1)
+        b = torch.from_numpy(synth.hash_uniform("b", (cout,), 1000 + i))
+        ref = F.conv2d(x, wt, b, padding=1)
+        ref = F.relu(ref) if act == _lib.ACT_RELU else F.leaky_relu(ref, 0.2) if act == _lib.ACT_LRELU else ref
+        kw = {}
+        if rng.integers(0, 2):
+            r1 = rq("r1", (n, cout, h, w))
+            ref = ref * 0.2 + r1
+            kw = dict(alpha=0.2, res1=ops.Planes.from_nchw(r1, dt))
+        pc = ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=cout_tile)
+        try:
+            got = ops.conv3x3(ops.Planes.from_nchw(x, dt), pc, act=act, rows_per_wave=mb, **kw).to_nchw().cpu()
+        except RuntimeError as e:   # a combination the kernel declines, with its message
+            print(f"declined: dt={dt} cin={cin} cout={cout} tile={cout_tile} mb={mb}: {e}", flush=True)
+            continue
+        err, scale = float((got - ref).abs().max()), max(float(ref.abs().max()), 1e-6)
+        if got.shape != ref.shape or err > OP_TOL[dt] * scale:
+            bad += 1
+            print(f"FAIL conv dt={dt} cin={cin} cout={cout} tile={cout_tile} mb={mb} n={n} h={h} w={w} act={act} "
+                  f"res={bool(kw)}: {err:.3g} > {OP_TOL[dt]:.2g} * {scale:.3g}", flush=True)
+        ih, iw, oh, ow = (int(v) for v in rng.integers(1, 200, 4))
+        img = synth.random_image(ih, iw, 2000 + i)
+        want = O.resize_bilinear_u8(img, ow, oh)
+        have = ops.resize_bilinear_u8(torch.from_numpy(img).cuda(), ow, oh).cpu().numpy()
+        if not np.array_equal(have, want):
+            bad += 1
+            print(f"FAIL resize {iw}x{ih} -> {ow}x{oh}: max diff {np.abs(have.astype(int) - want).max()}", flush=True)
+    return bad
 
 ARCHS = [
     dict(arch="rrdbnet", num_block=1, scale=4, input="unit"),
@@ -79,6 +130,11 @@ def main():
                   flush=True)
         if (i + 1) % 10 == 0:
             print(f"{i + 1}/{cases} cases, {bad} failed, {time.time() - t0:.0f} s", flush=True)
+    if len(sys.argv) > 3:
+        op_cases = int(sys.argv[3])
+        op_bad = fuzz_ops(rng, op_cases)
+        print(f"fuzz_shapes: {op_cases} standalone convolutions and resizes, {op_bad} failed")
+        bad += op_bad
     print(f"fuzz_shapes: {cases} cases, seed {seed}, {bad} failed; worst f32 error {worst32:.3f} of its bound, "
           f"worst f16 result {worst_lsb:.0f} LSB / {worst_db:.1f} dB")
     sys.exit(1 if bad else 0)
