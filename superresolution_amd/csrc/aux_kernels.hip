@@ -28,10 +28,12 @@ __device__ __forceinline__ float pre_affine(const float* m, float b, const float
     return ((m[0] * raw[0] + m[1] * raw[1]) + m[2] * raw[2]) + b;
 }
 
+template <int IN_KIND>
 __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
     // one thread = one pixel x 16 output channels (one half plane = 32 bytes of halves).  The channel
     // group is uniform over the workgroup, so the weights come through scalar loads; the 27 inputs
-    // of the pixel are converted once and reused for the 16 outputs.
+    // of the pixel are converted once and reused for the 16 outputs.  (8, 32 and 64 outputs per thread
+    // are all slower: the kernel lives on having many waves to hide its scalar weight fetches.)
     const long long hw = (long long)p.h * p.w;
     const long long pixn = (long long)blockIdx.x * 256 + threadIdx.x;
     if (pixn >= (long long)p.n * hw) return;
@@ -45,21 +47,23 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
+            // no branch per tap: a tap outside the image loads the nearest pixel inside it (always a valid
+            // address) and is zeroed afterwards, so that all loads of a thread are in flight together
             const int yy = y + ky - 1, xx = x + kx - 1;
+            const unsigned keep = (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) ? 0xffffffffu : 0u;
+            const int yc = min(max(yy, 0), p.h - 1), xc = min(max(xx, 0), p.w - 1);
             float* vt = v + (ky * 3 + kx) * 3;
-            vt[0] = vt[1] = vt[2] = 0.f;
-            if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
-                float raw[3];
-                if (p.in_kind == SRMI_IN_U8_NHWC) {
-                    const unsigned char* s = (const unsigned char*)p.in + ((long long)n * hw + (long long)yy * p.w + xx) * 3;
-                    raw[0] = (float)s[0]; raw[1] = (float)s[1]; raw[2] = (float)s[2];
-                } else {
-                    const float* s = (const float*)p.in + (long long)n * 3 * hw + (long long)yy * p.w + xx;
-                    raw[0] = s[0]; raw[1] = s[hw]; raw[2] = s[2 * hw];
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) vt[c] = pre_affine(p.pre_mat + 3 * c, p.pre_bias[c], raw);
+            float raw[3];
+            if (IN_KIND == SRMI_IN_U8_NHWC) {
+                const unsigned char* s = (const unsigned char*)p.in + ((long long)n * hw + (long long)yc * p.w + xc) * 3;
+                raw[0] = (float)s[0]; raw[1] = (float)s[1]; raw[2] = (float)s[2];
+            } else {
+                const float* s = (const float*)p.in + (long long)n * 3 * hw + (long long)yc * p.w + xc;
+                raw[0] = s[0]; raw[1] = s[hw]; raw[2] = s[2 * hw];
             }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)  // zeroed through a bit mask: a select here comes back as a branch per tap
+                vt[c] = __uint_as_float(__float_as_uint(pre_affine(p.pre_mat + 3 * c, p.pre_bias[c], raw)) & keep);
         }
     }
     float acc[16];
@@ -385,8 +389,11 @@ extern "C" int srmi_conv_first(const srmi_conv_first_desc_t* d, void* hip_stream
     p.out = to_view(d->out); p.out2 = to_view(d->out2);
     const long long total = (long long)d->n * d->h * d->w;
     if ((total + 255) / 256 > 0x7fffffffll) SRMI_FAIL("srmi_conv_first: problem too large");
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)(d->cout / 16)), dim3(256), 0,
-                       (hipStream_t)hip_stream, p);
+    const dim3 grid((unsigned)((total + 255) / 256), (unsigned)(d->cout / 16));
+    if (d->in_kind == SRMI_IN_U8_NHWC)
+        hipLaunchKernelGGL(conv_first_kernel<SRMI_IN_U8_NHWC>, grid, dim3(256), 0, (hipStream_t)hip_stream, p);
+    else
+        hipLaunchKernelGGL(conv_first_kernel<SRMI_IN_F32_NCHW>, grid, dim3(256), 0, (hipStream_t)hip_stream, p);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
