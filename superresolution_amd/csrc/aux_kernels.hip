@@ -291,42 +291,29 @@ __global__ __launch_bounds__(256) void nearest_up2_kernel(TView in, TView out, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// float NCHW <-> planes (any plane dtype).  One thread = one pixel x 4 channels.
+// float NCHW <-> planes (any plane dtype).  One thread = one pixel x 8 channels (16 bytes of a half
+// plane); blockIdx.y = (image, channel group), so no index is divided.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* in, TView out, int n_img, int c, int c_pad,
-                                                             long long hw) {
-    const int groups = c_pad >> 2;
-    const long long total = (long long)n_img * groups * hw;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const long long pix = idx % hw;
-        long long t = idx / hw;
-        const int g = (int)(t % groups);
-        const int n = (int)(t / groups);
-        float v[4];
+__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* in, TView out, int c, int groups, long long hw) {
+    const int n = blockIdx.y / groups, g = blockIdx.y - n * groups;
+    const float* src = in + ((long long)n * c + g * 8) * hw;
+    for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < hw; pix += (long long)gridDim.x * 256) {
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = g * 4 + j;
-            v[j] = ch < c ? in[((long long)n * c + ch) * hw + pix] : 0.f;
-        }
-        store4(out, n, pix, g * 4, v);
+        for (int j = 0; j < 8; ++j) v[j] = g * 8 + j < c ? src[j * hw + pix] : 0.f;
+        store8(out, n, pix, g * 8, v);
     }
 }
 
-__global__ __launch_bounds__(256) void planes_to_nchw_kernel(TView in, float* out, int n_img, int c, long long hw) {
-    const int groups = (c + 3) >> 2;
-    const long long total = (long long)n_img * groups * hw;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const long long pix = idx % hw;
-        long long t = idx / hw;
-        const int g = (int)(t % groups);
-        const int n = (int)(t / groups);
-        float v[4];
-        load4(in, n, pix, g * 4, v);
+__global__ __launch_bounds__(256) void planes_to_nchw_kernel(TView in, float* out, int c, int groups, long long hw) {
+    const int n = blockIdx.y / groups, g = blockIdx.y - n * groups;
+    float* dst = out + ((long long)n * c + g * 8) * hw;
+    for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < hw; pix += (long long)gridDim.x * 256) {
+        float v[8];
+        load8(in, n, pix, g * 8, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = g * 4 + j;
-            if (ch < c) out[((long long)n * c + ch) * hw + pix] = v[j];
-        }
+        for (int j = 0; j < 8; ++j)
+            if (g * 8 + j < c) dst[j * hw + pix] = v[j];
     }
 }
 
@@ -490,8 +477,11 @@ extern "C" int srmi_nchw_to_planes(const float* in, const srmi_tensor_t* out, in
     const int cpb = dtype_cpb(out->dtype);
     const int c_pad = (c + cpb - 1) / cpb * cpb;
     const long long hw = (long long)h * w;
-    hipLaunchKernelGGL(nchw_to_planes_kernel, dim3(grid_for(n * hw * (c_pad / 4))), dim3(256), 0, (hipStream_t)hip_stream,
-                       in, to_view(*out), n, c, c_pad, hw);
+    // every plane holds a multiple of 8 channels, so groups of 8 cover the padded channel count exactly
+    const long long blocks_y = (long long)n * (c_pad / 8);
+    if (n <= 0 || c <= 0 || hw <= 0 || blocks_y > 65535) SRMI_FAIL("srmi_nchw_to_planes: bad shape n=%d c=%d h=%d w=%d", n, c, h, w);
+    hipLaunchKernelGGL(nchw_to_planes_kernel, dim3(grid_for(hw, 256, 1024), (unsigned)blocks_y), dim3(256), 0,
+                       (hipStream_t)hip_stream, in, to_view(*out), c, c_pad / 8, hw);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
@@ -500,8 +490,11 @@ extern "C" int srmi_planes_to_nchw(const srmi_tensor_t* in, float* out, int n, i
                                    void* hip_stream) {
     if (!in || !in->ptr || !out) SRMI_FAIL("srmi_planes_to_nchw: null pointer");
     const long long hw = (long long)h * w;
-    hipLaunchKernelGGL(planes_to_nchw_kernel, dim3(grid_for(n * hw * ((c + 3) / 4))), dim3(256), 0, (hipStream_t)hip_stream,
-                       to_view(*in), out, n, c, hw);
+    const int groups = (c + 7) / 8;
+    const long long blocks_y = (long long)n * groups;
+    if (n <= 0 || c <= 0 || hw <= 0 || blocks_y > 65535) SRMI_FAIL("srmi_planes_to_nchw: bad shape n=%d c=%d h=%d w=%d", n, c, h, w);
+    hipLaunchKernelGGL(planes_to_nchw_kernel, dim3(grid_for(hw, 256, 1024), (unsigned)blocks_y), dim3(256), 0,
+                       (hipStream_t)hip_stream, to_view(*in), out, c, groups, hw);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
