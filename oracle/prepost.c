@@ -9,6 +9,10 @@
  *   or_postprocess_unit     realesrgan.cpp:110-130
  *   or_postprocess_range    edsr.cpp:101-122
  *   or_resize_bilinear      edsr.cpp:46-94 (identical in rcan.cpp and realesrgan.cpp:53-101)
+ *
+ * Pinning: tests/golden/prepost_cpp_ref.npz holds outputs of the reference runners' own C++ functions
+ * (compiled from the reference's sources by `make -C oracle ref`, run by tools/make_golden_prepost_cpp.py);
+ * tests/test_oracle.py checks these restatements against them bit for bit.
  */
 #include <stdint.h>
 

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("ops.npz", "prepost_ref.npz"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("ops.npz", "prepost_ref.npz", "prepost_cpp_ref.npz"))
 
 
 def load_case(tag):
@@ -71,6 +71,12 @@ def build_model(meta, compute_dtype, trunk_f32=True):
 # absolute (edsr/mtk/python/test/test_pytorch.py:187) = 3.9e-6 of the image scale.
 def f32_tol(meta):
     return 1e-4 if meta["input"] == "unit" else 1e-3
+
+
+def prepost_cpp_ref():
+    """Outputs of the reference C++ runners' own preprocess_image / postprocess_image / resize_image
+    (tools/make_golden_prepost_cpp.py)."""
+    return np.load(os.path.join(GOLDEN, "prepost_cpp_ref.npz"))
 
 
 def prepost_ref():

@@ -188,6 +188,47 @@ def test_u8_tail_matches_the_reference_python_postprocess():
     assert np.array_equal(got.cpu().numpy(), O.post_range(t, O.ROUND_HALF_UP))
 
 
+def test_pre_post_resize_match_the_reference_cpp_functions():
+    """The fused u8 pre-processing of the first layer, the u8 tail in the runners' rounding mode (half-up) and the
+    resize kernel against outputs of the reference C++ runners' own preprocess_image / postprocess_image /
+    resize_image (tests/golden/prepost_cpp_ref.npz, tools/make_golden_prepost_cpp.py), bit for bit.  Convolutions
+    with a single 1.0 on the centre tap hand the values through unchanged."""
+    from tests import helpers as H
+    z = H.prepost_cpp_ref()
+    mean255 = (z["rgb_mean"] * np.float32(255.0)).astype(np.float32)
+    # post-processing: f32 tensor -> identity conv -> u8 tail
+    wt = np.zeros((3, 8, 3, 3), np.float32)
+    for c in range(3):
+        wt[c, c, 1, 1] = 1.0
+    pc = ops.PackedConv(wt, np.zeros(3, np.float32), _lib.F32, cout_tile=32)
+
+    def tail(t, **kw):
+        x = torch.zeros((1, 8, t.shape[1], t.shape[2]))
+        x[0, :3] = torch.from_numpy(t)
+        return ops.conv3x3(ops.Planes.from_nchw(x, _lib.F32), pc,
+                           tail=dict(mode=_lib.TAIL_U8_NHWC, round=_lib.ROUND_HALF_UP, **kw)).cpu().numpy()[0]
+
+    for n in ("edsr", "rcan"):
+        assert np.array_equal(tail(z["t"], lo=0.0, hi=255.0, scale=1.0), z[f"post_{n}_zero"]), n
+        assert np.array_equal(tail(z["t"], lo=0.0, hi=255.0, scale=1.0, bias=mean255), z[f"post_{n}_mean"]), n
+    assert np.array_equal(tail(z["t_unit"], lo=0.0, hi=1.0, scale=255.0), z["post_realesrgan"])
+    # pre-processing: u8 image -> first layer whose output channel c is the centre tap of input channel c
+    w0 = np.zeros((32, 3, 3, 3), np.float32)
+    for c in range(3):
+        w0[c, c, 1, 1] = 1.0
+    img = torch.from_numpy(z["img"])[None].cuda()
+    got = ops.conv_first(img, w0, np.zeros(32, np.float32), _lib.F32, pre_bias=-mean255).to_nchw().cpu().numpy()[0, :3]
+    assert np.array_equal(got, z["pre_edsr"]) and np.array_equal(got, z["pre_rcan"])
+    got = ops.conv_first(img, w0, np.zeros(32, np.float32), _lib.F32,
+                         pre_mat=np.eye(3, dtype=np.float32) * np.float32(1.0 / 255.0)).to_nchw().cpu().numpy()[0, :3]
+    assert np.array_equal(got, z["pre_realesrgan"])
+    # resize
+    for i, (ih, iw, oh, ow) in enumerate(z["resize_cases"].tolist()):
+        src = synth.random_image(ih, iw, 300 + i)
+        got = ops.resize_bilinear_u8(torch.from_numpy(src).cuda(), ow, oh).cpu().numpy()
+        assert np.array_equal(got, z[f"resize_{i}"]), (ih, iw, oh, ow)
+
+
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
 @pytest.mark.parametrize("mb", [2, 3])
 def test_chansum(dt, name, tol, mb):
