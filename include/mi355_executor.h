@@ -63,13 +63,20 @@ public:
         if (!ex_) return false;
         return srmi_executor_run(ex_, inputs.data(), inputs.size(), outputs.data(), outputs.size()) == 0;
     }
-    size_t GetInputSize(size_t index) const { return srmi_executor_input_size(ex_, index); }
-    size_t GetOutputSize(size_t index) const { return srmi_executor_output_size(ex_, index); }
+    /* Bytes of tensor `index` as dense float32, from the constructor's shapes, so that they are valid
+     * before Initialize() as in the reference (neuron_executor.cpp:498-520); 0 when out of range. */
+    size_t GetInputSize(size_t index) const { return index < input_shapes_.size() ? Bytes(input_shapes_[index]) : 0; }
+    size_t GetOutputSize(size_t index) const { return index < output_shapes_.size() ? Bytes(output_shapes_[index]) : 0; }
     size_t GetNumInputs() const { return input_shapes_.size(); }
     size_t GetNumOutputs() const { return output_shapes_.size(); }
     bool IsInitialized() const { return ex_ != nullptr; }
 
 private:
+    static size_t Bytes(const std::vector<uint32_t>& shape) {
+        size_t n = sizeof(float);
+        for (uint32_t d : shape) n *= d;
+        return n;
+    }
     std::string model_path_, name_;
     std::vector<std::vector<uint32_t>> input_shapes_, output_shapes_;
     srmi_executor_t* ex_ = nullptr;

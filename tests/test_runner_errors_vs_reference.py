@@ -63,3 +63,20 @@ def test_error_paths_return_what_the_reference_returns(m, tmp_path):
     assert got == want
     # the documented difference between the runners (edsr.cpp:185-187 against realesrgan.cpp:197-199)
     assert want["release(uninitialised ctx)"] == (-1 if m == "realesrgan" else 0)
+
+
+def test_executor_class_behaves_like_the_reference_class_before_initialisation():
+    """Mi355Executor against the reference's NeuronExecutor (neuron_executor.h:85-117, its own .cpp compiled where it
+    lies): tensor counts and byte sizes from the constructor's shapes, Run() before Initialize(), Initialize() on a
+    missing model file (oracle/ref_executor_compare.cpp)."""
+    ref_src = "/root/reference/edsr/mtk/cpp/jni/src"
+    out = os.path.join(ROOT, "oracle", "_ref", "executor_compare")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    lib_dir = os.path.join(ROOT, "superresolution_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + ref_src,
+                    os.path.join(ROOT, "oracle", "ref_executor_compare.cpp"), os.path.join(ref_src, "mtk_npu", "neuron_executor.cpp"),
+                    "-L" + lib_dir, "-lsrmi355", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-ldl", "-o", out], check=True)
+    r = subprocess.run([out], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-2000:], r.stderr[-1000:])
+    assert r.returncode == 0 and "executor semantics match" in r.stdout
