@@ -3,7 +3,8 @@ boundaries (rows: multiples of 8 / 12, columns: multiples of 32, each -1 / 0 / +
 batches), f32 engine against the CPU oracle at the f32 bound, f16 engine at <= 1 LSB / >= 50 dB on the u8
 output.  Then, with a third argument, that many standalone convolutions (random channel counts, tile height, cout tile,
 activation, residual, dtype, image size and batch) against torch's fp32 conv2d on operands rounded to the compute
-type, and as many bilinear u8 resizes at random sizes against the oracle (bit-exact).
+type, an int8 convolution for every fourth of them against the exact integer convolution, and as many bilinear u8
+resizes at random sizes against the oracle (bit-exact).
 Prints one line per failing case and a summary; exit status 1 if anything failed.
 
     python tools/fuzz_shapes.py [cases] [seed] [op_cases]
@@ -58,6 +59,22 @@ def fuzz_ops(rng, cases):
             bad += 1
             print(f"FAIL conv dt={dt} cin={cin} cout={cout} tile={cout_tile} mb={mb} n={n} h={h} w={w} act={act} "
                   f"res={bool(kw)}: {err:.3g} > {OP_TOL[dt]:.2g} * {scale:.3g}", flush=True)
+        if i % 4 == 0:
+            # int8 x int8 -> int32 is exact: the scaled f32 output must equal the integer convolution to 1e-6
+            cin8, mb8 = 32 * int(rng.integers(1, 7)), int(rng.choice([2, 3]))
+            cout8 = 32 * int(rng.integers(1, 3))
+            ints = lambda key, shape: np.clip(np.rint(synth.hash_uniform(key, shape, 3000 + i) * 127), -127, 127).astype(np.float32)
+            xq, wq = torch.from_numpy(ints("x8", (n, cin8, h, w))), torch.from_numpy(ints("w8", (cout8, cin8, 3, 3)))
+            ws = (synth.hash_uniform("ws", (cout8,), 3000 + i) * 0.5 + 1.0).astype(np.float32) * 1e-4
+            b8 = synth.hash_uniform("b8", (cout8,), 3000 + i).astype(np.float32)
+            ref8 = F.conv2d(xq.double(), wq.double(), None, padding=1) * torch.from_numpy(ws).double().view(1, -1, 1, 1) \
+                + torch.from_numpy(b8).double().view(1, -1, 1, 1)
+            got8 = ops.conv3x3(ops.Planes.from_nchw(xq, _lib.I8, qscale=1.0), ops.PackedConv(wq.numpy(), b8, _lib.I8, cout_tile=32, wscale=ws),
+                               out_dtype=_lib.F32, rows_per_wave=mb8).to_nchw().cpu().double()
+            err8 = float((got8 - ref8).abs().max())
+            if got8.shape != ref8.shape or err8 > 1e-6 * max(float(ref8.abs().max()), 1e-6):
+                bad += 1
+                print(f"FAIL int8 conv cin={cin8} cout={cout8} mb={mb8} n={n} h={h} w={w}: {err8:.3g}", flush=True)
         ih, iw, oh, ow = (int(v) for v in rng.integers(1, 200, 4))
         img = synth.random_image(ih, iw, 2000 + i)
         want = O.resize_bilinear_u8(img, ow, oh)
