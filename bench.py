@@ -51,15 +51,20 @@ def build_model(arch, dtype, trunk_f32, device, growth_round8=True):
     return m, sd
 
 
+def cpu_threads():
+    """16 = the CPU share of a one-GPU box of this pool (its OMP_NUM_THREADS); os.cpu_count() there reports the
+    whole machine.  On a smaller host all cores are used."""
+    return min(16, os.cpu_count() or 1)
+
+
 def cpu_baseline(arch, sd, h, w, threads):
-    """Oracle forward (fp32, PyTorch CPU ops = the reference's arithmetic) incl. u8 pre/post on a
-    bounded sample; returns (output Mpix/s, description)."""
+    """Oracle forward (fp32, PyTorch CPU ops = the reference's arithmetic) incl. u8 pre/post on a bounded sample:
+    one whole frame of the configuration, 1 warm-up + median of 3 passes (the reference times exactly this call,
+    edsr/mtk/python/test/test_pytorch.py:105-108).  Returns (record, frame, oracle output of that frame)."""
     from oracle import sr_oracle as O
     from superresolution_amd import synth
     torch.set_num_threads(threads)
-    # one whole bench frame: 5.5-6.6 TFLOP, a few seconds per pass on 16 cores
-    sh, sw = h, w
-    img = synth.smooth_image(sh, sw, 1)
+    img = synth.smooth_image(h, w, 1)
 
     def run():
         with torch.no_grad():
@@ -77,7 +82,25 @@ def cpu_baseline(arch, sd, h, w, threads):
         ts.append(time.perf_counter() - t0)
     t = sorted(ts)[1]
     mpix = out.shape[1] * out.shape[2] / 1e6
-    return mpix / t, f"1 whole bench frame {sw}x{sh}, 1 warm-up + median of 3 passes, {t:.2f} s/frame"
+    rec = {"value": round(mpix / t, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
+           "s_per_frame": round(t, 3),
+           "cores_note": "the box's per-GPU CPU share (16) or the host's core count if smaller",
+           "sample": f"1 whole frame {w}x{h} of this configuration, 1 warm-up + median of 3 passes, {t:.2f} s/frame"}
+    return rec, img, out[0]
+
+
+def parity_vs_oracle(eng, img, ref):
+    """One whole frame through the engine (u8 in HBM -> u8 in HBM, the runners' half-up rounding) against the CPU
+    oracle's output of the same frame: max u8 difference and PSNR.  A report beside the throughput, not a test."""
+    from superresolution_amd import _lib
+    got = eng.forward_u8(torch.from_numpy(img).cuda(), _lib.ROUND_HALF_UP).cpu().numpy().astype(np.int32)
+    d = np.abs(got - ref.astype(np.int32))
+    mse = float(np.mean(d.astype(np.float64) ** 2))
+    psnr = float(10 * np.log10(255.0 ** 2 / max(mse, 1e-12)))
+    return {"max_u8_diff": int(d.max()), "psnr_db": round(psnr, 2),
+            "frac_above_1_lsb": float(round((d > 1).mean(), 8)),
+            "meets_tolerance": bool(d.max() <= 1 and psnr >= 50.0),
+            "tolerance": "u8 diff <= 1 LSB and PSNR >= 50 dB against the fp32 CPU oracle, one whole frame"}
 
 
 def conv_launches_per_frame(model):
@@ -92,17 +115,21 @@ def conv_launches_per_frame(model):
     return 15 * model.num_block + 1 + (2 if eng.scale == 4 else 1) + 2
 
 
-def pmc_traffic(arch, dtype):
-    """Bytes per conv launch between L2 and the fabric (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) from the committed
-    PMC passes of this workload, or None."""
+def pmc_record(arch, dtype):
+    """The committed PMC figures of this workload (profiles/pmc_traffic.json), or {}: `traffic_bytes_per_launch` =
+    bytes per conv launch between L2 and the fabric (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), `mfma_busy` = the share
+    of resident SIMD-cycles in which the matrix pipe works (SQ_VALU_MFMA_BUSY_CYCLES over SQ_BUSY_CYCLES, one lane)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
-        rec = rec.get(f"{arch}:{dtype}")
-        return rec and rec["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        return None
+        return rec.get(f"{arch}:{dtype}") or {}
+    except (OSError, ValueError):
+        return {}
+
+
+def pmc_traffic(arch, dtype):
+    return pmc_record(arch, dtype).get("traffic_bytes_per_launch")
 
 
 def w8a8_peak(model, flops_frame, h, w):
@@ -115,7 +142,7 @@ def w8a8_peak(model, flops_frame, h, w):
     return round(flops_frame / t, 1)
 
 
-def w8a8_config(h, w, batch, steps, device, lanes=3):
+def w8a8_config(h, w, batch, steps, device, lanes=3, oracle_frame=None):
     """RealESRGAN_x4plus with int8 dense blocks (the reference's w8a8 deployment): throughput, and accuracy against the
     f16 engine on the same frames (the reference quotes its INT8 model against its FP16 one: 33.34 dB)."""
     from superresolution_amd import _lib, synth
@@ -143,7 +170,13 @@ def w8a8_config(h, w, batch, steps, device, lanes=3):
     flops_frame = eng.flops(h, w)
     tflops = flops_frame * frames / sec / 1e12
     peak = w8a8_peak(model, flops_frame, h, w)
+    parity = None
+    if oracle_frame is not None:
+        parity = parity_vs_oracle(eng, *oracle_frame)
+        parity["tolerance"] = ("reported against the f16 engine's bound (<= 1 LSB, >= 50 dB); the reference's own INT8 "
+                               "deployment reports 33.34 dB (realesrgan/rknn/MIGRATION_REPORT.md:368-376)")
     return {"workload": f"rrdbnet x4 {w}x{h}->{w * 4}x{h * 4}, batch {batch}, int8 dense blocks (w8a8), f16 elsewhere",
+            "parity_vs_oracle": parity,
             "dtype": "i8/f16", "value": round(frames * h * 4 * w * 4 / 1e6 / sec, 2), "unit": "Mpix/s",
             "ms_per_frame": round(sec / frames * 1e3, 4),
             "psnr_vs_f16_engine_db": {"smooth": round(psnr[0], 2), "noise": round(psnr[1], 2)},
@@ -152,14 +185,20 @@ def w8a8_config(h, w, batch, steps, device, lanes=3):
                          "frac": round(tflops / peak, 4)}}
 
 
-def side_config(arch, dtype, h, w, batch, steps, device, lanes=3):
+def side_config(arch, dtype, h, w, batch, steps, device, lanes=3, cpu=None):
     """A BASELINE configuration other than the headline one, measured in the same process (u8 in HBM -> u8 in
     HBM, HIP-event time on the launch stream): output Mpix/s, ms per frame and the conv kernel's MFMA fraction."""
     from superresolution_amd import _lib, synth
-    model, _ = build_model(arch, dtype, False, device)
+    model, sd = build_model(arch, dtype, False, device)
     eng = model.engine()
     eng.set_lanes(lanes)
     scale = eng.scale
+    # cpu: None (no CPU pass), or a dict shared by the precisions of one configuration: the oracle runs once
+    parity = None
+    if cpu is not None:
+        if "rec" not in cpu:
+            cpu["rec"], cpu["img"], cpu["ref"] = cpu_baseline(arch, sd, h, w, cpu_threads())
+        parity = parity_vs_oracle(eng, cpu["img"], cpu["ref"])
     imgs = torch.from_numpy(synth.random_image(h, w, 300, n=batch)).cuda()
     out = torch.empty((batch, h * scale, w * scale, 3), dtype=torch.uint8, device="cuda")
     eng.forward_u8(imgs, _lib.ROUND_HALF_UP, out=out)
@@ -177,7 +216,12 @@ def side_config(arch, dtype, h, w, batch, steps, device, lanes=3):
            "dtype": dtype, "value": round(frames * h * scale * w * scale / 1e6 / sec, 2), "unit": "Mpix/s",
            "ms_per_frame": round(sec / frames * 1e3, 4),
            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                        "frac": round(tflops / MFMA_PEAK_TFLOPS[dtype], 4)}}
+                        "frac": round(tflops / MFMA_PEAK_TFLOPS[dtype], 4),
+                        "traffic": pmc_traffic(arch, dtype), "mfma_busy": pmc_record(arch, dtype).get("mfma_busy")}}
+    if cpu is not None:
+        rec["parity_vs_oracle"] = parity
+        rec["meets_tolerance"] = parity["meets_tolerance"]
+        rec["cpu_baseline"] = cpu["rec"]
     del eng, model
     torch.cuda.empty_cache()
     return rec
@@ -499,6 +543,7 @@ def main():
             "ms_per_frame_per_gpu": round(dev_s / (batch * args.steps) * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.model, args.dtype),
+                         "mfma_busy": pmc_record(args.model, args.dtype).get("mfma_busy"),
                          "kernel": "conv3x3_kernel<dtype,rows,cout_blocks> (all instantiations; "
                                    f"{flops_frame / 1e12:.3f} algorithmic TFLOP per frame over HIP-event device time)",
                          "launches_per_frame": launches,
@@ -510,6 +555,12 @@ def main():
                                          "frac": round(flops_frame / serial / 1e12 / peak, 4),
                                          "avg_launch_us": round(serial / launches * 1e6, 3),
                                          "note": "one lane: launches run back to back, as under rocprofv3 --kernel-trace"}
+        oracle_frame = None
+        if not args.no_cpu_baseline and world == 1 and not args.tiles:
+            cb, cimg, cref = cpu_baseline(args.model, sd, h, w, cpu_threads())
+            rec["cpu_baseline"] = cb
+            oracle_frame = (cimg, cref)
+            rec["parity_vs_oracle"] = parity_vs_oracle(eng, cimg, cref)
         if not args.no_side_configs and world == 1 and not args.tiles and not args.w8a8:
             g = vendor_gemm_tflops(args.dtype)
             if g:
@@ -524,23 +575,26 @@ def main():
             rec["e2e_host"] = hp
             # free the headline model's workspace before the other networks take theirs
             side_steps = max(2, args.steps // 5)
+            # every BASELINE configuration carries its own CPU time (the oracle on one whole frame of it) and the
+            # engine's parity against that frame's oracle output; EDSR's two precisions share one CPU pass
+            with_cpu = not args.no_cpu_baseline
+            edsr_cpu = {} if with_cpu else None
             rec["other_configs"] = {
-                "edsr_x4_256x256_batch32_bf16": side_config("edsr", "bf16", 256, 256, 32, side_steps, local_rank),
-                "edsr_x4_256x256_batch32_f16": side_config("edsr", "f16", 256, 256, 32, side_steps, local_rank),
-                "rcan_x4_510x339_f16": side_config("rcan", "f16", 339, 510, 12, side_steps, local_rank),
-                "rrdbnet_x4_510x339_w8a8": w8a8_config(339, 510, 12, side_steps, local_rank),
+                "edsr_x4_256x256_batch32_f16": side_config("edsr", "f16", 256, 256, 32, side_steps, local_rank, cpu=edsr_cpu),
+                "edsr_x4_256x256_batch32_bf16": side_config("edsr", "bf16", 256, 256, 32, side_steps, local_rank, cpu=edsr_cpu),
+                "rcan_x4_510x339_f16": side_config("rcan", "f16", 339, 510, 12, side_steps, local_rank,
+                                                   cpu={} if with_cpu else None),
+                "rrdbnet_x4_510x339_w8a8": w8a8_config(339, 510, 12, side_steps, local_rank,
+                                                       oracle_frame=oracle_frame if h == 339 and w == 510 else None),
             }
+            if with_cpu:
+                # BASELINE configuration 1 is the reference's own CPU-runnable case: EDSR x4 256x256 -> 1024x1024,
+                # PyTorch CPU forward, batch 1 (edsr/mtk/python/test/test_pytorch.py:105-108)
+                rec["other_configs"]["edsr_x4_256x256_cpu_reference_path_batch1"] = dict(
+                    edsr_cpu["rec"], workload="edsr x4 256x256->1024x1024, fp32 PyTorch CPU forward, batch 1 (the oracle)")
             big = tiled_1080p_config(max(1, side_steps // 2), local_rank)
             rec["other_configs"]["rrdbnet_x4_1080p_whole_f16"] = big["whole"]
             rec["other_configs"]["rrdbnet_x4_1080p_tiled_2x4_halo32_f16"] = big["tiled"]
-        if not args.no_cpu_baseline and world == 1 and not args.tiles:
-            # 16 = the CPU share of a one-GPU box of this pool (its OMP_NUM_THREADS); os.cpu_count() there reports
-            # the whole machine.  On a smaller host all cores are used.
-            threads = min(16, os.cpu_count() or 1)
-            v, sample = cpu_baseline(args.model, sd, h, w, threads)
-            rec["cpu_baseline"] = {"value": round(v, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
-                                   "cores_note": "the box's per-GPU CPU share (16) or the host's core count if smaller",
-                                   "sample": sample}
         print(json.dumps(rec))
     if dist is not None:
         dist.destroy_process_group()

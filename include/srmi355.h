@@ -282,7 +282,15 @@ int srmi_model_finalize(srmi_model_t* m);
 
 /* Calls on ONE model are serialised: each call is ordered behind the previous call on that model (an
  * event wait on the caller's stream), whatever streams or host threads they come from, because they
- * share the model's workspace.  Different models are independent.
+ * share the model's workspace.  Different models are independent.  Two exceptions:
+ *   - srmi_model_forward_u8_noalloc takes no part in this ordering (it waits for and records nothing): all
+ *     models on a GPU share that GPU's static array, and the CALLER keeps calls that use it from overlapping
+ *     (one stream, or events of its own);
+ *   - a call made while `hip_stream` is being captured into a HIP graph neither waits for nor records the
+ *     model's ordering event (an event recorded outside a capture cannot be waited for inside it): the graph
+ *     orders the call, the caller keeps other work on the model away from the graph's replays, and the
+ *     workspace must exist before the capture (srmi_model_reserve, or one eager call of the same shape) —
+ *     a captured call that would have to allocate fails with a message saying so.
  * forward(x): f32 NCHW [n][3][h][w] -> f32 NCHW [n][3][h*scale][w*scale], device pointers.
  * EDSR/RCAN: 0..rgb_range domain including MeanShift; RRDBNet: [0,1], no clamp. */
 int srmi_model_forward_f32(srmi_model_t* m, const float* in, float* out, int n, int h, int w,
@@ -362,11 +370,15 @@ int srmi_model_set_growth_round8(srmi_model_t* m, int on);
 int srmi_model_calibrate_begin(srmi_model_t* m);
 int srmi_model_calibrate_end(srmi_model_t* m);
 int srmi_model_set_w8a8(srmi_model_t* m, int on);
+/* 1 while the int8 form is the one that runs, else 0 (also 0 for a calibrated model switched back to f16). */
+int srmi_model_get_w8a8(const srmi_model_t* m);
 /* Number of calibrated tensors and their max |x| (order: per dense block, trunk input then x1..x4). */
 int srmi_model_calibration(const srmi_model_t* m, float* absmax, int capacity);
 /* Install activation ranges recorded earlier (srmi_model_calibration) and switch w8a8 on: how a deployed model
- * skips the calibration run, as the reference ships the already quantised .rknn file. */
+ * skips the calibration run, as the reference ships the already quantised .rknn file.  The _ex form installs the
+ * ranges and leaves the model in the form `enable_w8a8` names (0: calibrated, but running in f16). */
 int srmi_model_set_calibration(srmi_model_t* m, const float* absmax, int n);
+int srmi_model_set_calibration_ex(srmi_model_t* m, const float* absmax, int n, int enable_w8a8);
 
 /* Algorithmic conv FLOPs (2*Cin*Cout*9 per output pixel of every conv) of one forward at
  * (h, w) input size. */

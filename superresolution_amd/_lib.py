@@ -79,7 +79,7 @@ EXPORTS = [
     "srmi_model_key", "srmi_model_finalize", "srmi_model_forward_f32", "srmi_model_forward_u8",
     "srmi_model_workspace_bytes", "srmi_model_set_sweep", "srmi_model_set_fused_attention", "srmi_model_set_lanes", "srmi_model_set_growth_round8", "srmi_model_flops", "srmi_model_set_rgb_shift",
     "srmi_absmax", "srmi_model_calibrate_begin", "srmi_model_calibrate_end", "srmi_model_set_w8a8",
-    "srmi_model_calibration", "srmi_model_set_calibration", "srmi_model_reserve", "srmi_model_forward_u8_host", "srmi_model_reserve_host",
+    "srmi_model_calibration", "srmi_model_set_calibration", "srmi_model_set_calibration_ex", "srmi_model_get_w8a8", "srmi_model_reserve", "srmi_model_forward_u8_host", "srmi_model_reserve_host",
     "srmi_model_forward_u8_noalloc", "srmi_static_workspace_bytes",
     "edsr_init", "edsr_release", "edsr_inference", "edsr_inference_ex",
     "rcan_init", "rcan_release", "rcan_inference", "rcan_inference_ex",
@@ -151,6 +151,8 @@ def lib():
             L.srmi_model_set_w8a8.argtypes = [C.c_void_p, C.c_int]
             L.srmi_model_calibration.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
             L.srmi_model_set_calibration.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            L.srmi_model_set_calibration_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            L.srmi_model_get_w8a8.argtypes = [C.c_void_p]
         L.srmi_model_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.srmi_static_workspace_bytes.argtypes = []
         L.srmi_static_workspace_bytes.restype = C.c_size_t

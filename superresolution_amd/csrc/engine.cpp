@@ -26,6 +26,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "common.h"
@@ -77,7 +78,8 @@ struct srmi_model {
     std::map<std::string, HostTensor> tensors;
     bool finalized = false;
 
-    std::map<std::string, ConvW> convs;
+    // transparent comparator: the per-launch lookups pass a string_view and allocate nothing on the host
+    std::map<std::string, ConvW, std::less<>> convs;
     std::vector<CaW> cas;
     float* first_w = nullptr;  // [27][nf]
     float* first_b = nullptr;
@@ -118,7 +120,7 @@ struct srmi_model {
     bool calibrating = false, calibrated = false, w8a8 = false;
     float* calib_dev = nullptr;
     std::vector<float> absmax;
-    std::map<std::string, ConvW> convs_q;
+    std::map<std::string, ConvW, std::less<>> convs_q;
     std::vector<void*> dev_allocs_q;
     int calib_slots() const { return 5 * (3 * d.n_blocks + 1); }
     float act_scale(int g, int j) const {
@@ -372,12 +374,12 @@ struct Exec {
         float* scale;      // [ns][c]
     };
 
-    int conv(const std::string& name, const srmi_tensor_t& in, int h, int w, int act, bool up2,
+    int conv(const char* name, const srmi_tensor_t& in, int h, int w, int act, bool up2,
              float alpha, const srmi_tensor_t* res1, float beta, const srmi_tensor_t* res2,
              const srmi_tensor_t* out, const srmi_tensor_t* out2, float* chansum = nullptr, int force_mb = 0,
              const Gate* gate = nullptr, const Attention* att = nullptr) {
-        auto it = m->convs.find(name);
-        if (it == m->convs.end()) SRMI_FAIL("internal: conv '%s' not uploaded", name.c_str());
+        auto it = m->convs.find(std::string_view(name));
+        if (it == m->convs.end()) SRMI_FAIL("internal: conv '%s' not uploaded", name);
         const ConvW& cw = it->second;
         srmi_conv_desc_t d;
         memset(&d, 0, sizeof(d));
@@ -405,11 +407,11 @@ struct Exec {
     }
 
     // int8 form of a dense-block conv (w8a8 mode)
-    int conv_q(const std::string& name, const srmi_tensor_t& in, int h, int w, int act, float alpha,
+    int conv_q(const char* name, const srmi_tensor_t& in, int h, int w, int act, float alpha,
                const srmi_tensor_t* res1, float beta, const srmi_tensor_t* res2, const srmi_tensor_t* out,
                const srmi_tensor_t* out2) {
-        auto it = m->convs_q.find(name);
-        if (it == m->convs_q.end()) SRMI_FAIL("internal: int8 conv '%s' not prepared", name.c_str());
+        auto it = m->convs_q.find(std::string_view(name));
+        if (it == m->convs_q.end()) SRMI_FAIL("internal: int8 conv '%s' not prepared", name);
         const ConvW& cw = it->second;
         srmi_conv_desc_t d;
         memset(&d, 0, sizeof(d));
@@ -434,9 +436,11 @@ struct Exec {
         return srmi_absmax(&t, ns, h, w, c, m->calib_dev + slot, stream);
     }
 
-    int tail(const std::string& name, const srmi_tensor_t& in, int h, int w, int mode, void* dst,
+    int tail(const char* name, const srmi_tensor_t& in, int h, int w, int mode, void* dst,
              const float* mat, const float* bias, float lo, float hi, float scale, int round) {
-        const ConvW& cw = m->convs[name];
+        auto it = m->convs.find(std::string_view(name));
+        if (it == m->convs.end()) SRMI_FAIL("internal: conv '%s' not uploaded", name);
+        const ConvW& cw = it->second;
         srmi_conv_desc_t d;
         memset(&d, 0, sizeof(d));
         d.dtype = m->cdt();
@@ -933,6 +937,12 @@ static int ensure_resources(srmi_model* m, size_t bytes, int lanes, bool lane_st
     return 0;
 }
 
+static bool hip_failed(hipError_t e, const char* what) {
+    if (e == hipSuccess) return false;
+    set_error("%s failed: %s", what, hipGetErrorString(e));
+    return true;
+}
+
 // static_ws: run in the per-device static array on the caller's stream only, without any allocation,
 // stream or event creation (srmi_model_forward_u8_noalloc); otherwise in the model's own workspace.
 static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t stream, bool static_ws = false) {
@@ -947,6 +957,15 @@ static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t st
     size_t lane_bytes = 0;
     if (plan_bytes(m, n, h, w, static_ws ? 1 : m->lanes, &ns, &lanes, &lane_bytes)) return -1;
     char* ws = nullptr;
+    // A call that is being captured into a HIP graph must not wait for, or record, events that live outside the
+    // capture (`last_done` was recorded by an earlier eager call): such a call is ordered by the graph alone, and
+    // the caller keeps other work on this model away from the graph's replays.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        capture = hipStreamCaptureStatusNone;
+    }
+    const bool capturing = capture != hipStreamCaptureStatusNone;
     if (static_ws) {
         if (!m->static_ws) SRMI_FAIL("forward: the static workspace of device %d was not resolved", m->d.device);
         if (lane_bytes > SRMI_STATIC_WS_BYTES)
@@ -955,14 +974,33 @@ static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t st
                       (unsigned long long)SRMI_STATIC_WS_BYTES);
         ws = m->static_ws;
     } else {
+        if (capturing && (lane_bytes * lanes > m->ws_bytes || !m->last_done || (lanes > 1 && !m->lane_stream[lanes - 1])))
+            SRMI_FAIL("forward: the stream is being captured and this call would have to allocate its workspace or lanes: "
+                      "call srmi_model_reserve(n, h, w) (or run one eager forward of this shape) before the capture");
         if (ensure_resources(m, lane_bytes * lanes, lanes)) return -1;
         ws = m->ws;
         // order this call behind the previous one on this model, whatever stream that ran on
-        if (m->has_last_done) SRMI_HIP(hipStreamWaitEvent(stream, m->last_done, 0));
+        if (m->has_last_done && !capturing) SRMI_HIP(hipStreamWaitEvent(stream, m->last_done, 0));
     }
+    // Lanes fork from the caller's stream and join it again on EVERY way out of this function, failed HIP calls
+    // included: the caller's stream is never left unordered against work already issued on a lane.
+    struct LaneJoin {
+        srmi_model* m;
+        hipStream_t stream;
+        int forked = 0;
+        ~LaneJoin() {
+            for (int l = 0; l < forked; ++l) {
+                if (hipEventRecord(m->lane_done[l], m->lane_stream[l]) == hipSuccess)
+                    (void)hipStreamWaitEvent(stream, m->lane_done[l], 0);
+            }
+        }
+    } join{m, stream};
     if (lanes > 1) {
         SRMI_HIP(hipEventRecord(m->fork, stream));
-        for (int l = 0; l < lanes; ++l) SRMI_HIP(hipStreamWaitEvent(m->lane_stream[l], m->fork, 0));
+        for (int l = 0; l < lanes; ++l) {
+            SRMI_HIP(hipStreamWaitEvent(m->lane_stream[l], m->fork, 0));
+            join.forked = l + 1;
+        }
     }
     const size_t in_img = io.in_kind == SRMI_IN_U8_NHWC ? (size_t)h * w * 3 : (size_t)h * w * 3 * sizeof(float);
     const size_t hh = (size_t)h * m->d.scale, ww = (size_t)w * m->d.scale;
@@ -984,13 +1022,19 @@ static int forward(srmi_model* m, IoSpec io, int n, int h, int w, hipStream_t st
         rc = run_plan(m, A, &ex, &io, h, w);
     }
     if (lanes > 1) {
-        // join even after a failed launch so that the caller's stream stays ordered behind the lanes
-        for (int l = 0; l < lanes; ++l) {
-            SRMI_HIP(hipEventRecord(m->lane_done[l], m->lane_stream[l]));
-            SRMI_HIP(hipStreamWaitEvent(stream, m->lane_done[l], 0));
+        // join now (the guard then has nothing left to do), so that `last_done` below lies behind the lanes
+        const int forked = join.forked;
+        join.forked = 0;
+        for (int l = 0; l < forked; ++l) {
+            if (hipEventRecord(m->lane_done[l], m->lane_stream[l]) != hipSuccess ||
+                hipStreamWaitEvent(stream, m->lane_done[l], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("forward: joining lane %d failed", l);
+                rc = -1;
+            }
         }
     }
-    if (!static_ws) {
+    if (!static_ws && !capturing) {
         SRMI_HIP(hipEventRecord(m->last_done, stream));
         m->has_last_done = true;
     }
@@ -1104,7 +1148,9 @@ static int forward_u8_host(srmi_model* m, const uint8_t* in, uint8_t* out, int n
         if (i >= lanes && drain(i - lanes)) { rc = -1; break; }
         memcpy(s.pin_in, in + (size_t)i * in_bytes, in_bytes);
         hipStream_t st = m->lane_stream[l];
-        SRMI_HIP(hipMemcpyAsync(s.dev_in, s.pin_in, in_bytes, hipMemcpyHostToDevice, st));
+        // failures inside the loop leave through the drain below: frames already issued still read and write
+        // the pinned buffers, and the next call would overwrite them
+        if (hip_failed(hipMemcpyAsync(s.dev_in, s.pin_in, in_bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync (input frame)")) { rc = -1; break; }
         Exec ex;
         ex.m = m;
         ex.stream = st;
@@ -1116,8 +1162,13 @@ static int forward_u8_host(srmi_model* m, const uint8_t* in, uint8_t* out, int n
         io.out = s.dev_out;
         rc = run_plan(m, A, &ex, &io, h, w);
         if (rc) break;
-        SRMI_HIP(hipMemcpyAsync(s.pin_out, s.dev_out, out_bytes, hipMemcpyDeviceToHost, st));
-        SRMI_HIP(hipEventRecord(s.done, st));
+        if (hip_failed(hipMemcpyAsync(s.pin_out, s.dev_out, out_bytes, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (output frame)") ||
+            hip_failed(hipEventRecord(s.done, st), "hipEventRecord")) {
+            // the frame's completion cannot be waited for through its event: wait for the whole device instead
+            (void)hipDeviceSynchronize();
+            rc = -1;
+            break;
+        }
         issued = i + 1;
     }
     // frames issued - lanes .. issued - 1 are still in their slots
@@ -1428,6 +1479,12 @@ extern "C" int srmi_model_calibrate_end(srmi_model_t* m) {
 }
 
 extern "C" int srmi_model_set_calibration(srmi_model_t* m, const float* absmax, int n) {
+    return srmi_model_set_calibration_ex(m, absmax, n, 1);
+}
+
+extern "C" int srmi_model_get_w8a8(const srmi_model_t* m) { return (m && m->w8a8) ? 1 : 0; }
+
+extern "C" int srmi_model_set_calibration_ex(srmi_model_t* m, const float* absmax, int n, int enable_w8a8) {
     if (!m || !absmax) SRMI_FAIL("srmi_model_set_calibration: null argument");
     if (!m->finalized) SRMI_FAIL("srmi_model_set_calibration: srmi_model_finalize has not been called");
     if (m->d.arch != SRMI_ARCH_RRDBNET || m->d.dtype != SRMI_F16)
@@ -1444,7 +1501,7 @@ extern "C" int srmi_model_set_calibration(srmi_model_t* m, const float* absmax, 
     m->calibrating = false;
     if (prepare_w8a8(m)) return -1;
     m->calibrated = true;
-    m->w8a8 = true;
+    m->w8a8 = enable_w8a8 != 0;
     return 0;
 }
 

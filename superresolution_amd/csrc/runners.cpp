@@ -139,6 +139,15 @@ static int load_model_body(FILE* f, long file_size, const char* path, int want_a
             return -1;
         }
     }
+    // which arithmetic this context runs in (a calibrated weight file switches the dense blocks to int8)
+    {
+        const char* g8 = getenv("SRMI_GROWTH_ROUND8");
+        const bool round8 = d.arch == SRMI_ARCH_RRDBNET && d.dtype == SRMI_F16 && !(g8 && !strcmp(g8, "0"));
+        fprintf(stderr, "[INFO] %s: precision %s%s%s, f32 residual trunk, device %d\n", path,
+                d.dtype == SRMI_F32 ? "f32" : d.dtype == SRMI_BF16 ? "bf16" : "f16",
+                srmi_model_get_w8a8(m) ? " + w8a8 dense blocks (int8, calibrated ranges from the weight file)" : "",
+                (round8 && !srmi_model_get_w8a8(m)) ? " (dense-block grown channels at 8 significant bits)" : "", device);
+    }
     *out = m;
     *desc_out = d;
     return 0;

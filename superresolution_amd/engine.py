@@ -126,10 +126,16 @@ class Engine:
             lib().srmi_model_calibration(self._h, a.ctypes.data, n)
         return a
 
-    def set_calibration(self, absmax):
-        """Install recorded activation ranges (see calibration()) and switch the int8 mode on."""
+    def set_calibration(self, absmax, w8a8=True):
+        """Install recorded activation ranges (see calibration()); the int8 mode is switched on unless w8a8=False
+        (calibrated, but running in f16 until set_w8a8(True))."""
         a = np.ascontiguousarray(np.asarray(absmax, dtype=np.float32))
-        check(lib().srmi_model_set_calibration(self._h, a.ctypes.data, a.size), "srmi_model_set_calibration")
+        check(lib().srmi_model_set_calibration_ex(self._h, a.ctypes.data, a.size, int(bool(w8a8))),
+              "srmi_model_set_calibration")
+
+    def w8a8(self):
+        """True while the int8 dense blocks are the form that runs."""
+        return bool(lib().srmi_model_get_w8a8(self._h))
 
     def set_w8a8(self, on=True):
         """Switch a calibrated model between its int8 dense blocks and plain f16."""

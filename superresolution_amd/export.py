@@ -3,8 +3,9 @@
 The reference runners load a vendor-compiled `.dla` blob (edsr.cpp:126-157); the MI355X runners
 load this container instead: the architecture hyper-parameters plus the state_dict tensors in the
 reference's key layout, float32 little endian ("SRMIW001", see csrc/runners.cpp).  A model calibrated for the int8
-mode carries its activation ranges in an optional trailer ("SRMIQ001", int32 count, float32 values): the runner
-then starts in w8a8 mode, as the reference's runner loads an already quantised .rknn file.
+mode, and with that mode switched on when it is saved, carries its activation ranges in an optional trailer
+("SRMIQ001", int32 count, float32 values): the runner then starts in w8a8 mode, as the reference's runner loads
+an already quantised .rknn file.  A model running in f16 when it is saved comes back in f16.
 """
 from __future__ import annotations
 
@@ -40,9 +41,12 @@ def save_weights(model, path):
             f.write(struct.pack("<i", a.ndim))
             f.write(struct.pack(f"<{a.ndim}q", *a.shape))
             f.write(a.tobytes())
-        # activation ranges of a calibrated model (only looked up when an engine already exists)
+        # activation ranges of a calibrated model whose int8 form is switched ON (only looked up when an engine
+        # already exists): a reader of the trailer starts in w8a8 mode, so a model that was calibrated and then
+        # switched back to f16 (set_w8a8(False)) is written without it and comes back in f16
         eng = getattr(model, "_srmi_engine", None)
-        cal = eng.calibration() if eng is not None and getattr(model, "_srmi_stamp", None) == model._param_stamp() else ()
+        live = eng is not None and getattr(model, "_srmi_stamp", None) == model._param_stamp()
+        cal = eng.calibration() if live and eng.w8a8() else ()
         if len(cal):
             f.write(b"SRMIQ001")
             f.write(struct.pack("<i", len(cal)))

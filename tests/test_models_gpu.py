@@ -56,10 +56,14 @@ def test_u8_runner_path_full_depth(arch, dtype):
     psnr = O.psnr_u8(g, ref)
     print(f"{arch} {dtype}: max u8 diff {diff.max()}, differing {100 * (diff != 0).mean():.3f}%, PSNR {psnr:.2f} dB, "
           f"clamped lo {100 * (ref == 0).mean():.1f}% hi {100 * (ref == 255).mean():.1f}%")
-    # f32 / f16 meet the task's half-precision bound (<= 1 LSB, PSNR >= 50 dB).  bf16 keeps only 8
-    # significant bits per conv operand: through 351 (RRDBNet) / 411 (RCAN) convolutions it stays
-    # above 50 dB but a few pixels move by 2-3 LSB, so f16 is the default half type.
-    assert diff.max() <= (1 if dtype != "bf16" else 4)
+    # One bound for every dtype: u8 diff <= 1 LSB and PSNR >= 50 dB.  f32 / f16 meet it.  bf16 keeps only 8
+    # significant bits per conv operand: through 351 (RRDBNet) / 411 (RCAN) convolutions it stays above 50 dB but
+    # a few pixels move by 2-3 LSB, so f16 is the default half type and a bf16 run that misses the bound is
+    # reported as an expected failure with its measured error, never as a pass against a looser bound.
+    if dtype == "bf16" and (diff.max() > 1 or psnr < 50.0):
+        pytest.xfail(f"bf16 operands miss the half-precision bound on {arch}: max u8 diff {diff.max()} LSB "
+                     f"(> 1 LSB on {100 * (diff > 1).mean():.4f} % of the samples), PSNR {psnr:.2f} dB")
+    assert diff.max() <= 1
     assert psnr >= 50.0
 
 
@@ -118,9 +122,9 @@ def test_edsr_batch_configuration_full_size():
 
 def test_edsr_batch_configuration_full_size_bf16():
     """The configuration the baseline names in bf16 (EDSR x4, 256x256, batch 32), run in bf16 at full size and
-    depth: its error against the oracle is RECORDED and bounded by what bf16 operands deliver, which is not the
-    1-LSB bound: with 8 significant bits per conv operand in the 0..255 domain a few pixels move by 2-3 LSB while
-    the PSNR stays above 50 dB.  The 1-LSB / 50 dB half-precision bound is met by the f16 engine (test above)."""
+    depth against the half-precision bound (<= 1 LSB, >= 50 dB).  With 8 significant bits per conv operand in the
+    0..255 domain a few pixels move by 2 LSB while the PSNR stays above 50 dB: the run is then an EXPECTED FAILURE
+    whose reason carries the measured error.  The bound is met by the f16 engine (test above)."""
     meta = _u8_case("edsr")
     model, sd = H.build_model(meta, "bf16")
     torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -128,6 +132,7 @@ def test_edsr_batch_configuration_full_size_bf16():
     batch = torch.from_numpy(np.concatenate([imgs] * 16)).cuda()          # 32 frames
     out = model.engine().forward_u8(batch).cpu().numpy()
     assert out.shape == (32, 1024, 1024, 3)
+    worst = []
     for i, kind in enumerate(("smooth", "noise")):
         with torch.no_grad():
             ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(imgs[i])), O.ROUND_HALF_UP)[0]
@@ -135,9 +140,12 @@ def test_edsr_batch_configuration_full_size_bf16():
         psnr = O.psnr_u8(out[i], ref)
         print(f"edsr 256x256 batch 32 bf16 ({kind}): max u8 diff {diff.max()}, > 1 LSB on {100 * (diff > 1).mean():.4f} % of "
               f"the samples, differing {100 * (diff != 0).mean():.2f} %, PSNR {psnr:.2f} dB")
-        assert diff.max() <= 2 and (diff > 1).mean() < 1e-4 and psnr >= 54.0
+        worst.append((kind, int(diff.max()), float((diff > 1).mean()), float(psnr)))
     for i in range(32):
         assert np.array_equal(out[i], out[i % 2]), i
+    if any(m > 1 or ps < 50.0 for _, m, _, ps in worst):
+        pytest.xfail("EDSR x4 256x256 batch 32 in bf16 misses the <= 1 LSB / >= 50 dB bound: " +
+                     "; ".join(f"{k}: max {m} LSB, > 1 LSB on {100 * f:.4f} %, {ps:.2f} dB" for k, m, f, ps in worst))
 
 
 def test_rcan_configuration_full_size_frame():

@@ -1,4 +1,4 @@
-"""Multi-process CPU tests (gloo, world_size 2) of the frame / tile sharding logic with a stand-in
+"""Multi-process CPU tests (gloo, world_size 2 and 8) of the frame / tile sharding logic with a stand-in
 for the network (nearest x4 upscale, for which halo tiling is exact), plus geometry unit tests."""
 import os
 import socket
@@ -92,3 +92,43 @@ def test_tile_and_frame_sharding_world2_gloo():
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret[0][0] and ret[1][0]
     assert ret[0][1] + ret[1][1] == [0, 1, 2, 3, 4]
+
+
+def test_tile_assignment_of_the_1080p_grid_on_8_ranks():
+    """Tile mode of one 1920x1080 frame as the benchmark runs it (2 x 4 grid of 480x540 tiles + 32-pixel halo): on
+    eight ranks every rank owns exactly one tile, on 1 / 2 / 4 ranks equal shares, each tile exactly once."""
+    tiles = sharding.tile_grid(1080, 1920, 540, 480, 32)
+    assert len(tiles) == 8
+    for world in (1, 2, 4, 8):
+        owned = [list(sharding.shard_range(len(tiles), r, world)) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(8))
+        assert all(len(o) == 8 // world for o in owned)
+    assert [list(sharding.shard_range(8, r, 8)) for r in range(8)] == [[i] for i in range(8)]
+
+
+def _worker8(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # a small frame cut 2 x 4 like the 1080p grid: 8 tiles on 8 ranks, one each, gathered to rank 0
+        img = torch.from_numpy(synth.random_image(64, 128, 5))
+        assert len(sharding.tile_grid(64, 128, 32, 32, 4)) == 8
+        out = sharding.upscale_tiled_sharded(fake_forward, img, 4, 32, 32, 4, rank, world, batched=True)
+        frames = torch.from_numpy(synth.random_image(8, 12, 6, n=19))     # 19 frames: shares of 3 and 2
+        own, outs = sharding.upscale_frames_sharded(fake_forward, frames, rank, world)
+        ok = all(torch.equal(o, fake_forward(frames[i])) for i, o in zip(own, outs))
+        ok = ok and (torch.equal(out, fake_forward(img)) if rank == 0 else out is None)
+        ret[rank] = (bool(ok), list(own))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tile_and_frame_sharding_world8_gloo():
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world))
+    assert sum((ret[r][1] for r in range(world)), []) == list(range(19))
+    assert sorted(len(ret[r][1]) for r in range(world)) == [2] * 5 + [3] * 3

@@ -179,3 +179,69 @@ def test_w8a8_weight_file_round_trip_and_runner(tmp_path):
         finally:
             os.environ.pop("SRMI_W8A8", None)
         assert np.array_equal(got, expect), f"SRMI_W8A8={env}"
+
+
+def test_weight_file_of_a_model_switched_back_to_f16_comes_back_in_f16(tmp_path):
+    """A calibrated model whose int8 form is switched OFF when it is saved (set_w8a8(False), or an experimental
+    calibration that was not kept) must not come back in int8: the file then carries no calibration trailer, and
+    both readers (export.load_weights, the C runner) give the f16 bytes.  set_calibration(..., w8a8=False) installs
+    ranges without switching the mode on."""
+    import ctypes as C
+    import os
+    from superresolution_amd import export
+    from tests.test_runner_gpu import RealesrganCtx, _take
+    L = _lib.lib()
+    meta = dict(arch="rrdbnet", num_block=1, scale=4, seed=87, input="unit")
+    model, _ = H.build_model(meta, "f16")
+    img = synth.smooth_image(339, 510, 88)
+    f16_out = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    stats = model.quantize_w8a8(_calibration_frames(96, 128, 4))
+    eng = model.engine()
+    assert eng.w8a8()
+    q_out = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    assert not np.array_equal(q_out, f16_out)
+    eng.set_w8a8(False)
+    assert not eng.w8a8()
+    path = str(tmp_path / "RealESRGAN_x4plus_f16_again.srmi")
+    export.save_weights(model, path)
+    with open(path, "rb") as f:
+        assert b"SRMIQ001" not in f.read()[-(8 + 4 + 4 * len(stats)):]
+    again = export.load_weights(path, compute_dtype="f16")
+    assert not again.engine().w8a8() and len(again.engine().calibration()) == 0
+    assert np.array_equal(again.forward_u8(img, _lib.ROUND_HALF_UP).numpy(), f16_out)
+    os.environ.pop("SRMI_W8A8", None)
+    ctx = RealesrganCtx()
+    assert L.realesrgan_init(path.encode(), C.byref(ctx)) == 0, L.srmi_last_error()
+    out = C.c_void_p()
+    assert L.realesrgan_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), C.byref(out)) == 0
+    got = _take(out, 1356, 2040)
+    assert L.realesrgan_release(C.byref(ctx)) == 0
+    assert np.array_equal(got, f16_out)
+    # ranges installed without switching the mode on: still f16 until set_w8a8(True)
+    again.engine().set_calibration(stats, w8a8=False)
+    assert not again.engine().w8a8()
+    assert np.array_equal(again.forward_u8(img, _lib.ROUND_HALF_UP).numpy(), f16_out)
+    again.engine().set_w8a8(True)
+    assert np.array_equal(again.forward_u8(img, _lib.ROUND_HALF_UP).numpy(), q_out)
+
+
+def test_rrdbnet_w8a8_full_size_frame_against_the_oracle():
+    """The benchmark's w8a8 configuration (23 blocks, 510x339 -> 2040x1356, calibration on six synthetic frames of
+    that size) against the fp32 oracle on one whole frame.  <= 1 LSB is not required of int8; the recorded figures are
+    asserted at >= 50 dB (the half-precision bound of the f16 engine) with the maximum LSB difference printed; the
+    reference's own INT8 deployment reports 33.34 dB (realesrgan/rknn/MIGRATION_REPORT.md:368-376)."""
+    meta = dict(arch="rrdbnet", num_block=23, scale=4, seed=0, input="unit")
+    model, sd = H.build_model(meta, "f16", trunk_f32=False)
+    h, w = 339, 510
+    img = synth.smooth_image(h, w, 7)
+    f16_out = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    model.quantize_w8a8(_calibration_frames(h, w), batch=3)
+    got = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.post_unit(H.oracle_forward(meta, sd, O.pre_unit(img)), O.ROUND_HALF_UP)[0]
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    psnr = O.psnr_u8(got, ref)
+    print(f"rrdbnet b23 w8a8 at 510x339: PSNR {psnr:.2f} dB vs the fp32 oracle, max u8 diff {diff.max()}, "
+          f"> 1 LSB on {100 * (diff > 1).mean():.4f} % of the samples (f16 engine: {O.psnr_u8(f16_out, ref):.2f} dB)")
+    assert psnr >= 50.0 and diff.max() <= 3
