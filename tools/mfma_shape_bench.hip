@@ -11,6 +11,17 @@
 // stage: 15 KiB of "pixels" from a buffer that is L2-resident, Infinity-Cache-resident or HBM-sized, 9 KiB of "weights"
 // that every workgroup shares), first free-running (no wait ever), then with the stage's s_waitcnt vmcnt(0) + s_barrier.
 //
+// Third part ("winograd" cases, f16): the inner loop a Winograd F(2x2,3x3) form of the same convolution would run, at
+// equal ALGORITHMIC FLOPs.  One unit per wave = 32 output tiles of 2x2 pixels x 32 outputs x 16 input channels (one
+// stage): 16 ds_read_b128 of the 4x4 input patch (a lane holds its tile's 16 pixels for its 8 channels), the input
+// transform V = B^T d B in registers (32 packed-f16 vector adds of 8 channels = 128 v_pk_add_f16 per lane, every add
+// rounding to f16), 16 ds_read_b128 of transformed-weight fragments and 16 MFMAs 32x32x16 into 16 accumulators (one per
+// transform position: 256 accumulator registers, so one wave per SIMD and one workgroup per CU).  The direct loop
+// spends 36 MFMAs on the same 128 pixels x 32 outputs x 16 channels.  Software pipeline: the MFMAs of unit k read V(k)
+// while the adds transform unit k+1 in a second register array, two adds of 8 channels behind every MFMA; the register
+// an MFMA has just consumed is refilled at once with a patch fragment of unit k+2.  The output transform (24 f32 adds
+// per tile and output, once per convolution, not per stage) is not part of the loop.
+//
 // One "stage pair" per wave = the work of two 16-channel stages of a 3-row x 32-pixel x 32-output wave tile:
 // 54 MFMAs 32x32x16 or 108 MFMAs 16x16x32 (the two-plane-stage form, K = 32), 48 fragments of 1 KiB either way.
 #include <hip/hip_runtime.h>
@@ -189,6 +200,118 @@ __global__ __launch_bounds__(256, 3) void loop_kernel(const uint4* __restrict__ 
     }
 }
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// XFORM 1: the full loop.  XFORM 0: the same loads and MFMAs without the transform adds (what the matrix pipe and
+// the LDS alone sustain in this form).
+template <int XFORM>
+__global__ __launch_bounds__(256, 1) void wino_kernel(const uint4* __restrict__ src, float* __restrict__ sink, int units,
+                                                      unsigned long long* __restrict__ clk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < kLds / 16; i += 256) ((uint4*)smem)[i] = src[(blockIdx.x * (kLds / 16) + i) & 0xFFFFF];
+    __syncthreads();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int frags = kLds / 1024;
+    f32x16 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    auto frag = [&](int f) { return *(const h8*)(smem + (f % frags) * 1024 + lane * 16); };
+    h8 P[16], Q[16];   // one holds V of the unit being multiplied, the other the patch being transformed
+    h8 wf[8];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { P[k] = frag(k); Q[k] = frag(16 + k); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wf[k] = frag(32 + k);
+    // One unit: MFMAs read V (and refill each consumed register with a patch fragment of the unit after next), the
+    // adds turn X from patch d into V = B^T d B in place: steps 0-15 the four columns (B^T d), 16-31 the four rows.
+    auto step = [&](h8 (&X)[16], const int st) {
+        if constexpr (XFORM) {
+            const int half = st >> 4, line = (st >> 2) & 3, op = st & 3;
+            // element e of the line: column transform walks rows (stride 4) of column `line`, row transform walks
+            // the columns (stride 1) of row `line`
+            auto at = [&](int e) -> h8& { return half == 0 ? X[e * 4 + line] : X[line * 4 + e]; };
+            // in place, order chosen so that each input is still intact when it is read:
+            //   op0: x0 = x0 - x2 ; op1: x3 = x1 - x3 ; op2: tmp = x1 + x2, x2 = x2 - x1 (two adds) ; op3: x1 = tmp
+            if (op == 0) at(0) = at(0) - at(2);
+            else if (op == 1) at(3) = at(1) - at(3);
+            else if (op == 2) { const h8 t = at(1) + at(2); at(2) = at(2) - at(1); at(1) = t; }
+        }
+    };
+    auto unit = [&](h8 (&V)[16], h8 (&X)[16], const int it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[k & 7], V[k], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            V[k] = frag(it * 5 + k);                    // patch fragment of the unit after next
+            wf[k & 7] = frag(it * 3 + 24 + k);          // weight fragment for the multiply eight slots ahead
+            step(X, 2 * k);
+            step(X, 2 * k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int it = 0; it < units; it += 2) {
+        unit(P, Q, it);
+        unit(Q, P, it + 1);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[k][i];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += (float)P[k][0] + (float)Q[k][1];
+    if (s == 123.456f) sink[blockIdx.x * 256 + tid] = s;
+    if (clk && lane == 0) {
+        const size_t o = ((size_t)blockIdx.x * 4 + (tid >> 6)) * 2;
+        clk[o] = __builtin_amdgcn_s_memtime() - c0;
+        clk[o + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
+template <int XFORM>
+static void run_wino(const char* name, const uint4* src, float* sink, unsigned long long* clk, double seconds) {
+    const int grid = 768, units = 6000;
+    auto k = wino_kernel<XFORM>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    double spent = 0;
+    while (spent < seconds) {
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 5; ++i) k<<<grid, 256, kLds>>>(src, sink, units, nullptr);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        spent += ms / 1e3;
+    }
+    CHECK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) k<<<grid, 256, kLds>>>(src, sink, units, i == reps - 1 ? clk : nullptr);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    // per wave and unit: 16 MFMAs issued; the direct form spends 36 on the same pixels, outputs and channels
+    const double issued = (double)reps * grid * 4 * units * 16.0 * 32768.0;
+    const double algorithmic = issued * 36.0 / 16.0;
+    std::vector<unsigned long long> h((size_t)grid * 4 * 2);
+    CHECK(hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (size_t i = 0; i < h.size(); i += 2)
+        if (h[i + 1]) ghz.push_back((double)h[i] / (double)h[i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    printf("{\"case\": \"%s\", \"tflops_algorithmic\": %.1f, \"frac_of_2500_algorithmic\": %.3f, \"tflops_issued\": %.1f, "
+           "\"ms_per_launch\": %.3f, \"in_kernel_clock_ghz\": %.3f}\n",
+           name, algorithmic / (ms / 1e3) / 1e12, algorithmic / (ms / 1e3) / 2.5e15, issued / (ms / 1e3) / 1e12, ms / reps,
+           ghz.empty() ? 0.0 : ghz[ghz.size() / 2]);
+    fflush(stdout);
+}
+
 template <int SHAPE, bool BF, int STAGING = 0>
 static void run_case(const char* name, const uint4* src, float* sink, unsigned long long* clk, double seconds,
                      const char* pix = nullptr, unsigned long long pix_bytes = 0) {
@@ -246,6 +369,15 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc((void**)&sink, 768 * 256 * 4));
     CHECK(hipMalloc((void**)&clk, 768 * 4 * 2 * 8));
     CHECK(hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice));
+    if (argc > 2 && !strcmp(argv[2], "winograd")) {
+        // A/B on one device in one run: the direct loop, the Winograd loop, the Winograd loop without its adds
+        for (int round = 0; round < 3; ++round) {
+            run_case<32, false>("direct 3x3, f16 32x32x16, operands from LDS", src, sink, clk, seconds);
+            run_wino<1>("winograd F(2x2,3x3), f16: 16 patch + 16 weight reads, 128 v_pk_add_f16, 16 MFMAs per unit", src, sink, clk, seconds);
+            run_wino<0>("winograd F(2x2,3x3) without the transform adds (loads and MFMAs only)", src, sink, clk, seconds);
+        }
+        return 0;
+    }
     const bool staging_only = argc > 2 && !strcmp(argv[2], "staging");
     for (int round = 0; round < 2 && !staging_only; ++round) {
         run_case<32, false>("f16 32x32x16", src, sink, clk, seconds);
