@@ -81,6 +81,8 @@ typedef struct {
  * draw measurably less power on operands with short significands, so tensors that tolerate it (the
  * grown channels x1..x4 of a dense block, realesrgan_model.py:27-30) are kept that way. */
 #define SRMI_TENSOR_ROUND8 1
+#define SRMI_ALGO_DIRECT 0
+#define SRMI_ALGO_WINOGRAD 1
 #define SRMI_CA_SLOTS 8   /* accumulators per image and channel of srmi_conv_desc_t::ca */
 
 /*
@@ -146,7 +148,12 @@ typedef struct {
     srmi_tensor_t in_gate;
     const float* gate;
     float gate_alpha;
-    int32_t reserved;
+    /* SRMI_ALGO_DIRECT (0): implicit GEMM over the nine taps.  SRMI_ALGO_WINOGRAD: Winograd F(2x2,3x3) — the same
+     * convolution with 16 instead of 36 multiplies per 2x2 output tile and input channel; f16 compute only, weights
+     * from srmi_pack_wino3x3, cin a multiple of 32, cout_tile 32, no in_up2 / gated input / pixel shuffle / tail / channel attention.  The
+     * input transform adds and the transformed weights are rounded to f16, so results differ from the direct form in
+     * the last bits (both stay within the half-precision parity bound of the networks). */
+    int32_t algo;
     srmi_tensor_t in_sum;
     /* Channel attention finished inside the convolution (CALayer, rcan_model.py:61-76): with ca.sums set, every
      * workgroup adds its tile's channel sums, as 44.20 fixed point, to sums[n][tile % SRMI_CA_SLOTS][c] (integer
@@ -176,6 +183,13 @@ size_t srmi_pack_conv3x3_bytes(int dtype, int cout, int cin, int cout_tile, int*
  * `bias` may be NULL (zeros). Output buffers are host memory. */
 int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, int ps_r,
                       const float* w_oihw, const float* bias, void* wpk_out, float* bias_out);
+
+/* Winograd form of the weights (srmi_conv_desc_t::algo == SRMI_ALGO_WINOGRAD, f16): U = G g G^T per (output, input)
+ * channel pair, computed in double precision and rounded once to f16, laid out as the kernel stages it:
+ * [cout tile of 32][stage of 16 input channels][transform position 16][channel half 2][output 32][8 halves].
+ * cin a multiple of 16, cout a multiple of 32 (padded rows are zero).  Bias as in srmi_pack_conv3x3 (cout_tile 32). */
+size_t srmi_pack_wino3x3_bytes(int cout, int cin, int* bias_floats);
+int srmi_pack_wino3x3(int cout, int cin, const float* w_oihw, const float* bias, void* wpk_out, float* bias_out);
 
 /*
  * First layer: 3-channel input -> cout channels.  Fuses the network's pre-processing
@@ -356,6 +370,12 @@ int srmi_model_set_lanes(srmi_model_t* m, int lanes);
  * result stays within the half-precision parity bound (u8 diff <= 1 LSB, PSNR >= 50 dB); 0 gives
  * plain f16 everywhere. */
 int srmi_model_set_growth_round8(srmi_model_t* m, int on);
+/* RRDBNet with f16 compute: 1 runs the 15 convolutions of every RRDB (realesrgan_model.py:13-49) in their Winograd
+ * F(2x2,3x3) form (SRMI_ALGO_WINOGRAD), 0 (default) in the direct form.  Takes effect at the next forward call; both
+ * forms of the weights are packed at srmi_model_finalize.  Frames of 8 rows or fewer always run the direct form.
+ * Both forms meet the half-precision parity bound; the direct form is the faster one on whole layers. */
+int srmi_model_set_winograd(srmi_model_t* m, int on);
+int srmi_model_get_winograd(const srmi_model_t* m);
 /*
  * w8a8 mode of RRDBNet (f16 models): the reference's low-precision deployment (realesrgan/rknn/python/convert.py:198-278,
  * quantized_dtype w8a8 with a calibration set of [0,1] NCHW images) on the int8 matrix cores.

@@ -32,6 +32,7 @@ class Tensor(C.Structure):
 
 
 TENSOR_ROUND8 = 1
+ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
 CA_SLOTS = 8   # SRMI_CA_SLOTS
 
 
@@ -47,7 +48,7 @@ class ConvDesc(C.Structure):
                 ("tail_mat", C.c_float * 9), ("tail_bias", C.c_float * 3),
                 ("tail_lo", C.c_float), ("tail_hi", C.c_float), ("tail_scale", C.c_float),
                 ("tail_round", C.c_int32), ("wscale", C.c_void_p),
-                ("in_gate", Tensor), ("gate", C.c_void_p), ("gate_alpha", C.c_float), ("reserved", C.c_int32),
+                ("in_gate", Tensor), ("gate", C.c_void_p), ("gate_alpha", C.c_float), ("algo", C.c_int32),
                 ("in_sum", Tensor),
                 ("ca_sums", C.c_void_p), ("ca_count", C.c_void_p), ("ca_w1", C.c_void_p), ("ca_b1", C.c_void_p),
                 ("ca_w2", C.c_void_p), ("ca_b2", C.c_void_p), ("ca_scale", C.c_void_p), ("ca_cr", C.c_int32),
@@ -72,6 +73,7 @@ class ModelDesc(C.Structure):
 EXPORTS = [
     "srmi_last_error", "srmi_device_count", "srmi_version",
     "srmi_conv3x3", "srmi_conv3x3_tiles", "srmi_pack_conv3x3_bytes", "srmi_pack_conv3x3",
+    "srmi_pack_wino3x3_bytes", "srmi_pack_wino3x3", "srmi_model_set_winograd", "srmi_model_get_winograd",
     "srmi_conv_first", "srmi_ca_scale", "srmi_ca_apply", "srmi_channel_sums",
     "srmi_pixel_shuffle", "srmi_nearest_up2", "srmi_nchw_to_planes", "srmi_planes_to_nchw",
     "srmi_resize_bilinear_u8",
@@ -106,6 +108,11 @@ def lib():
         L.srmi_pack_conv3x3_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.srmi_pack_conv3x3.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.srmi_pack_wino3x3_bytes.restype = C.c_size_t
+        L.srmi_pack_wino3x3_bytes.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.srmi_pack_wino3x3.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.srmi_model_set_winograd.argtypes = [C.c_void_p, C.c_int]
+        L.srmi_model_get_winograd.argtypes = [C.c_void_p]
         L.srmi_conv3x3.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
         L.srmi_conv3x3_tiles.argtypes = [C.c_int, C.c_int, C.c_int]
         L.srmi_conv_first.argtypes = [C.POINTER(ConvFirstDesc), C.c_void_p]

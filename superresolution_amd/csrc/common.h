@@ -98,3 +98,7 @@ int srmi_load_weight_file(const char* path, int want_arch, int device, srmi_mode
 
 // conv3x3.hip: per-device kernel attributes of every instantiation (current device)
 int srmi_conv3x3_prepare_device();
+// wino3x3.hip: the Winograd F(2x2,3x3) form of the convolution (srmi_conv_desc_t::algo == SRMI_ALGO_WINOGRAD)
+int srmi_wino3x3_prepare_device();
+int srmi_wino3x3_tile_rows();
+int srmi_wino3x3_launch(const srmi::ConvParams& p, hipStream_t stream);

@@ -47,6 +47,7 @@ struct HostTensor {
 };
 
 struct ConvW {
+    void* wpk_wino = nullptr;  // Winograd F(2x2,3x3) form of the same weights (RRDBNet dense blocks, f16), else null
     void* wpk = nullptr;
     float* bias = nullptr;
     float* wscale = nullptr;  // int8 convs: per-output-channel dequantisation scale
@@ -96,6 +97,10 @@ struct srmi_model {
     // RRDBNet, f16: the grown channels x1..x4 of every dense block (and the weights that multiply them)
     // carry 8 significant bits; the trunk keeps full f16 precision (see srmi_model_set_growth_round8)
     bool growth_round8 = true;
+    // RRDBNet, f16: the dense blocks' convolutions run in their Winograd F(2x2,3x3) form (srmi_model_set_winograd).
+    // Off by default: measured slower than the direct form on whole layers (its 256 accumulator registers allow one
+    // wave per SIMD, so nothing on the CU hides a workgroup's first loads and its epilogue).
+    bool winograd = false;
 
     // Independent sweeps of one call run on `lanes` internal streams that fork from and join the
     // caller's stream, so that one sweep's launch gaps, prologues and epilogues overlap another's
@@ -284,6 +289,19 @@ static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
         return -1;
     if (dev_upload(m, wp.data(), bytes, &cw.wpk)) return -1;
     if (dev_upload(m, bp.data(), nbias * sizeof(float), (void**)&cw.bias)) return -1;
+    // the dense blocks' convolutions also in their Winograd form (from the unrounded weights: the transformed
+    // weights are rounded once, to f16); same bias vector (32-wide tiles in both forms)
+    if (m->d.arch == SRMI_ARCH_RRDBNET && m->cdt() == SRMI_F16 && name.find(".rdb") != std::string::npos &&
+        cw.cout_tile == 32 && cw.cin % 32 == 0) {
+        int nb2 = 0;
+        const size_t wb = srmi_pack_wino3x3_bytes(cw.cout, cw.cin, &nb2);
+        if (wb && nb2 == nbias) {
+            std::vector<char> up(wb);
+            std::vector<float> b2(nb2);
+            if (srmi_pack_wino3x3(cw.cout, cw.cin, w.data.data(), b.data.data(), up.data(), b2.data())) return -1;
+            if (dev_upload(m, up.data(), wb, &cw.wpk_wino)) return -1;
+        }
+    }
     m->convs[name] = cw;
     return 0;
 }
@@ -390,6 +408,12 @@ struct Exec {
         d.rows_per_wave = force_mb ? force_mb : pick_rows_per_wave(m, h);
         d.in = in;
         d.wpk = cw.wpk; d.bias = cw.bias;
+        // Winograd form where it exists and applies (not while calibrating: the recorded ranges belong to the direct form)
+        if (m->winograd && cw.wpk_wino && !up2 && !gate && !att && !chansum && h > 8 && !m->calibrating) {
+            d.algo = SRMI_ALGO_WINOGRAD;
+            d.wpk = cw.wpk_wino;
+            d.rows_per_wave = 0;
+        }
         d.alpha = alpha; d.beta = beta;
         if (res1) d.res1 = *res1;
         if (res2) d.res2 = *res2;
@@ -1443,6 +1467,15 @@ extern "C" int srmi_model_set_growth_round8(srmi_model_t* m, int on) {
     m->growth_round8 = on != 0;
     return 0;
 }
+
+extern "C" int srmi_model_set_winograd(srmi_model_t* m, int on) {
+    if (!m) SRMI_FAIL("srmi_model_set_winograd: null model");
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    m->winograd = on != 0;
+    return 0;
+}
+
+extern "C" int srmi_model_get_winograd(const srmi_model_t* m) { return (m && m->winograd) ? 1 : 0; }
 
 extern "C" int srmi_model_calibrate_begin(srmi_model_t* m) {
     if (!m) SRMI_FAIL("srmi_model_calibrate_begin: null model");

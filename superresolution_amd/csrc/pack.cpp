@@ -117,3 +117,46 @@ extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, in
     }
     return 0;
 }
+
+// Winograd F(2x2,3x3): U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], per (output, input) channel pair.
+extern "C" size_t srmi_pack_wino3x3_bytes(int cout, int cin, int* bias_floats) {
+    if (cin <= 0 || cin % 16 || cout <= 0) return 0;
+    const int ntile = (cout + 31) / 32;
+    if (bias_floats) *bias_floats = ntile * 32;
+    return (size_t)ntile * (cin / 16) * 16 * 32 * kPixBytes;
+}
+
+extern "C" int srmi_pack_wino3x3(int cout, int cin, const float* w, const float* bias, void* wpk_out, float* bias_out) {
+    int nbias = 0;
+    const size_t bytes = srmi_pack_wino3x3_bytes(cout, cin, &nbias);
+    if (!bytes) SRMI_FAIL("srmi_pack_wino3x3: bad shape cout=%d cin=%d (cin must be a multiple of 16)", cout, cin);
+    if (!w || !wpk_out || !bias_out) SRMI_FAIL("srmi_pack_wino3x3: null pointer");
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nstage = cin / 16, ntile = nbias / 32;
+    char* out = (char*)wpk_out;
+    for (int t = 0; t < ntile; ++t)
+        for (int row = 0; row < 32; ++row) {
+            const int o = t * 32 + row;
+            for (int ci = 0; ci < cin; ++ci) {
+                double U[4][4] = {};
+                if (o < cout) {
+                    const float* g = w + ((size_t)o * cin + ci) * 9;   // g[ky][kx]
+                    double tmp[4][3];
+                    for (int a = 0; a < 4; ++a)
+                        for (int j = 0; j < 3; ++j) tmp[a][j] = G[a][0] * g[0 * 3 + j] + G[a][1] * g[1 * 3 + j] + G[a][2] * g[2 * 3 + j];
+                    for (int a = 0; a < 4; ++a)
+                        for (int b = 0; b < 4; ++b) U[a][b] = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
+                }
+                const int st = ci / 16, c = (ci % 16) / 8, e = ci % 8;
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) {
+                        const int xi = a * 4 + b;
+                        char* dst = out + ((((size_t)t * nstage + st) * 16 + xi) * 2 + c) * 512 + row * 16 + e * 2;
+                        const uint16_t hv = f32_to_f16((float)U[a][b]);
+                        memcpy(dst, &hv, 2);
+                    }
+            }
+        }
+    for (int q = 0; q < nbias; ++q) bias_out[q] = (q < cout && bias) ? bias[q] : 0.f;
+    return 0;
+}

@@ -82,6 +82,14 @@ class Engine:
         while loading (default) or a separate elementwise pass does; the results are the same bytes."""
         check(lib().srmi_model_set_fused_attention(self._h, int(bool(on))), "srmi_model_set_fused_attention")
 
+    def set_winograd(self, on=True):
+        """RRDBNet, f16 compute: run the dense blocks' convolutions in their Winograd F(2x2,3x3) form (True) or in the
+        direct form (False); takes effect at the next forward."""
+        check(lib().srmi_model_set_winograd(self._h, int(bool(on))), "srmi_model_set_winograd")
+
+    def winograd(self):
+        return bool(lib().srmi_model_get_winograd(self._h))
+
     def set_sweep(self, images_per_sweep):
         check(lib().srmi_model_set_sweep(self._h, int(images_per_sweep)), "srmi_model_set_sweep")
 

@@ -74,25 +74,36 @@ _NULL = Tensor()
 class PackedConv:
     """Weights of one 3x3 convolution in the kernel's device format."""
 
-    def __init__(self, weight, bias, dtype, cout_tile=None, ps_r=1, device="cuda", wscale=None):
+    def __init__(self, weight, bias, dtype, cout_tile=None, ps_r=1, device="cuda", wscale=None, winograd=False):
         """dtype I8: `weight` holds integer values in [-127, 127] and `wscale` the per-output-channel factor the
-        int32 accumulator is multiplied with (weight scale * input activation scale)."""
+        int32 accumulator is multiplied with (weight scale * input activation scale).
+        winograd: pack for the Winograd F(2x2,3x3) form of the convolution (f16, cout_tile 32)."""
         w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))
         cout, cin = w.shape[:2]
         assert w.shape[2:] == (3, 3)
         if cout_tile is None:
-            cout_tile = 32 if cout <= 32 else 64
+            cout_tile = 32 if (cout <= 32 or winograd) else 64
         self.cout, self.cin, self.dtype, self.cout_tile, self.ps_r = cout, cin, dtype, cout_tile, ps_r
+        self.algo = _lib.ALGO_WINOGRAD if winograd else _lib.ALGO_DIRECT
         nb = C.c_int(0)
-        nbytes = lib().srmi_pack_conv3x3_bytes(dtype, cout, cin, cout_tile, C.byref(nb))
+        b = None if bias is None else np.ascontiguousarray(np.asarray(bias, dtype=np.float32))
+        if winograd:
+            if dtype != F16 or cout_tile != 32 or ps_r != 1:
+                raise _lib.SrmiError("the Winograd form needs f16, cout_tile 32 and no pixel shuffle")
+            nbytes = lib().srmi_pack_wino3x3_bytes(cout, cin, C.byref(nb))
+        else:
+            nbytes = lib().srmi_pack_conv3x3_bytes(dtype, cout, cin, cout_tile, C.byref(nb))
         if nbytes == 0:
             raise _lib.SrmiError(f"cannot pack conv weight {w.shape} for dtype {dtype}")
         wp = np.empty(nbytes, dtype=np.uint8)
         bp = np.empty(nb.value, dtype=np.float32)
-        b = None if bias is None else np.ascontiguousarray(np.asarray(bias, dtype=np.float32))
-        check(lib().srmi_pack_conv3x3(dtype, cout, cin, cout_tile, ps_r, w.ctypes.data,
-                                      None if b is None else b.ctypes.data, wp.ctypes.data, bp.ctypes.data),
-              "pack_conv3x3")
+        if winograd:
+            check(lib().srmi_pack_wino3x3(cout, cin, w.ctypes.data, None if b is None else b.ctypes.data,
+                                          wp.ctypes.data, bp.ctypes.data), "pack_wino3x3")
+        else:
+            check(lib().srmi_pack_conv3x3(dtype, cout, cin, cout_tile, ps_r, w.ctypes.data,
+                                          None if b is None else b.ctypes.data, wp.ctypes.data, bp.ctypes.data),
+                  "pack_conv3x3")
         self.host_w, self.host_b = wp, bp
         self.s = None
         if device is not None:
@@ -124,6 +135,7 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
     d.dtype = pc.dtype
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, pc.cin, pc.cout
     d.in_up2, d.act, d.ps_r, d.cout_tile, d.rows_per_wave = int(up2), act, pc.ps_r, pc.cout_tile, rows_per_wave
+    d.algo = getattr(pc, "algo", _lib.ALGO_DIRECT)
     d.inp = x.view()
     d.wpk, d.bias = pc.w.data_ptr(), pc.b.data_ptr()
     d.wscale = pc.s.data_ptr() if pc.s is not None else None

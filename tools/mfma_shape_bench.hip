@@ -202,6 +202,20 @@ __global__ __launch_bounds__(256, 3) void loop_kernel(const uint4* __restrict__ 
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+// a - b on 8 halves as four v_pk_add_f16 with the second operand negated (the compiler splits a vector subtraction
+// of halves into scalar v_sub_f16)
+__device__ __forceinline__ h8 sub8(const h8& a, const h8& b) {
+    const u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned t;
+        asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x[i]), "v"(y[i]));
+        r[i] = t;
+    }
+    return __builtin_bit_cast(h8, r);
+}
+
 // XFORM 1: the full loop.  XFORM 0: the same loads and MFMAs without the transform adds (what the matrix pipe and
 // the LDS alone sustain in this form).
 template <int XFORM>
@@ -212,13 +226,12 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const uint4* __restrict__ 
     for (int i = tid; i < kLds / 16; i += 256) ((uint4*)smem)[i] = src[(blockIdx.x * (kLds / 16) + i) & 0xFFFFF];
     __syncthreads();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    constexpr int frags = kLds / 1024;
     f32x16 acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-    auto frag = [&](int f) { return *(const h8*)(smem + (f % frags) * 1024 + lane * 16); };
+    auto frag = [&](int f) { return *(const h8*)(smem + (f & 31) * 1024 + lane * 16); };   // ring over the first 32 KiB
     h8 P[16], Q[16];   // one holds V of the unit being multiplied, the other the patch being transformed
     h8 wf[8];
 #pragma unroll
@@ -235,26 +248,28 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const uint4* __restrict__ 
             auto at = [&](int e) -> h8& { return half == 0 ? X[e * 4 + line] : X[line * 4 + e]; };
             // in place, order chosen so that each input is still intact when it is read:
             //   op0: x0 = x0 - x2 ; op1: x3 = x1 - x3 ; op2: tmp = x1 + x2, x2 = x2 - x1 (two adds) ; op3: x1 = tmp
-            if (op == 0) at(0) = at(0) - at(2);
-            else if (op == 1) at(3) = at(1) - at(3);
-            else if (op == 2) { const h8 t = at(1) + at(2); at(2) = at(2) - at(1); at(1) = t; }
+            if (op == 0) at(0) = sub8(at(0), at(2));
+            else if (op == 1) at(3) = sub8(at(1), at(3));
+            else if (op == 2) { const h8 t = at(1) + at(2); at(2) = sub8(at(2), at(1)); at(1) = t; }
         }
     };
-    auto unit = [&](h8 (&V)[16], h8 (&X)[16], const int it) {
+    auto unit = [&](h8 (&V)[16], h8 (&X)[16], const int par) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[k & 7], V[k], acc[k], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            V[k] = frag(it * 5 + k);                    // patch fragment of the unit after next
-            wf[k & 7] = frag(it * 3 + 24 + k);          // weight fragment for the multiply eight slots ahead
+            // constant LDS offsets, as in a real kernel (patch and weight fragments of a stage sit at fixed places):
+            // no address arithmetic in the loop.  `par` = which of the two register arrays is V in this unit.
+            V[k] = frag(par * 16 + k);                  // patch fragment of the unit after next
+            wf[k & 7] = frag(par * 8 + 5 + k);          // weight fragment for the multiply eight slots ahead
             step(X, 2 * k);
             step(X, 2 * k + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     for (int it = 0; it < units; it += 2) {
-        unit(P, Q, it);
-        unit(Q, P, it + 1);
+        unit(P, Q, 0);
+        unit(Q, P, 1);
     }
     float s = 0.f;
 #pragma unroll
