@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import custom_ops  # noqa: F401  (registers torch.ops.srmi355.*)
 from ._lib import check, lib
 
 
@@ -191,15 +192,21 @@ class Engine:
               "srmi_model_forward_u8_host")
         return out
 
+    def handle(self) -> int:
+        """The srmi_model_t* as an integer: what torch.ops.srmi355.forward_f32 / forward_u8 take (custom_ops.py)."""
+        return int(self._h.value)
+
     def forward_f32(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-        """x: float32 NCHW on this engine's GPU -> float32 NCHW [n,3,h*scale,w*scale]."""
+        """x: float32 NCHW on this engine's GPU -> float32 NCHW [n,3,h*scale,w*scale].  Without `out` the call goes
+        through the registered operator torch.ops.srmi355.forward_f32 (same C entry point underneath)."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected [N,3,H,W], got {tuple(x.shape)}")
         x = x.to(self.device, torch.float32).contiguous()
+        if out is None:
+            return torch.ops.srmi355.forward_f32(self.handle(), self.scale, x)
         n, _, h, w = x.shape
         shape = (n, 3, h * self.scale, w * self.scale)
-        out = torch.empty(shape, dtype=torch.float32, device=self.device) if out is None else \
-            self._check_out(out, shape, torch.float32)
+        out = self._check_out(out, shape, torch.float32)
         if n == 0:      # an empty batch gives an empty result, as the reference modules do (nothing to launch)
             return out
         check(lib().srmi_model_forward_f32(self._h, x.data_ptr(), out.data_ptr(), n, h, w, self._stream()),
@@ -214,10 +221,12 @@ class Engine:
         if img.dim() != 4 or img.shape[3] != 3 or img.dtype != torch.uint8:
             raise ValueError(f"expected uint8 [N,H,W,3], got {img.dtype} {tuple(img.shape)}")
         img = img.to(self.device).contiguous()
+        if out is None:
+            y = torch.ops.srmi355.forward_u8(self.handle(), self.scale, img, int(round_mode))
+            return y[0] if squeeze else y
         n, h, w, _ = img.shape
         shape = (n, h * self.scale, w * self.scale, 3)
-        out = torch.empty(shape, dtype=torch.uint8, device=self.device) if out is None else \
-            self._check_out(out, shape, torch.uint8)
+        out = self._check_out(out, shape, torch.uint8)
         if n == 0:
             return out
         check(lib().srmi_model_forward_u8(self._h, img.data_ptr(), out.data_ptr(), n, h, w, round_mode,
@@ -237,6 +246,8 @@ class HipModule(nn.Module):
         self._srmi_device = device
         self._srmi_engine = None
         self._srmi_stamp = None
+        self._srmi_handle = None   # int handle and scale of the current engine, for the traced (torch.compile) path
+        self._srmi_scale = None
 
     # subclasses return the Engine constructor kwargs
     def _engine_config(self):
@@ -260,11 +271,21 @@ class HipModule(nn.Module):
             want = self._srmi_engine.keys()
             self._srmi_engine.load_state_dict({k: sd[k] for k in want})
             self._srmi_stamp = stamp
+            self._srmi_handle, self._srmi_scale = self._srmi_engine.handle(), int(self._srmi_engine.scale)
         return self._srmi_engine
 
     def forward(self, x):
         """f32 NCHW in -> f32 NCHW out, the reference modules' forward contract.  The result is
-        returned on the input's device."""
+        returned on the input's device.
+
+        Under torch.compile the call is one node, torch.ops.srmi355.forward_f32 on the engine built by the last eager
+        `model.engine()` / `model(x)` call (uploading weights is host work that cannot be traced): build the engine
+        once before compiling, and again after changing parameters."""
+        if torch.compiler.is_compiling():
+            if self._srmi_handle is None:
+                raise RuntimeError("call model.engine() (or run one eager forward) before torch.compile: the weights are "
+                                   "uploaded outside the traced region")
+            return torch.ops.srmi355.forward_f32(self._srmi_handle, self._srmi_scale, x)
         eng = self.engine()
         y = eng.forward_f32(x)
         return y if x.is_cuda else y.to(x.device)
