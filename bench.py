@@ -359,6 +359,11 @@ def main():
                     help="synthetic input: uniform-noise frames plus one smooth frame (default), noise only, smooth only")
     ap.add_argument("--no-fused-attention", action="store_true",
                     help="RCAN: separate elementwise pass per channel-attention block instead of the gated conv input")
+    ap.add_argument("--no-fused-rcab", action="store_true",
+                    help="RCAN: the two convolutions of a block as two launches instead of one kernel")
+    ap.add_argument("--winograd", action="store_true",
+                    help="RRDBNet f16: the dense blocks' convolutions in their Winograd F(2x2,3x3) form (slower on whole "
+                         "layers; kept for A/B runs)")
     ap.add_argument("--w8a8", action="store_true",
                     help="RRDBNet: calibrate on synthetic frames and run the dense blocks in int8 (a lower-precision "
                          "configuration of its own; never the headline)")
@@ -425,6 +430,10 @@ def main():
         engs[-1].set_sweep(args.sweep)
         if args.no_fused_attention:
             engs[-1].set_fused_attention(False)
+        if args.no_fused_rcab:
+            engs[-1].set_fused_rcab(False)
+        if args.winograd:
+            engs[-1].set_winograd(True)
         engs[-1].set_lanes(args.lanes)
         if args.w8a8:
             engs[-1].calibrate(np.stack([synth.smooth_image(h, w, 900 + i) for i in range(4)] +

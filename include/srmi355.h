@@ -214,6 +214,40 @@ typedef struct {
 int srmi_conv_first(const srmi_conv_first_desc_t* d, void* hip_stream);
 
 /*
+ * The body of a residual channel-attention block in one kernel (RCAB.forward, rcan_model.py:79-97):
+ *   x'  = in + gate_alpha * (in_gate * gate[n][c])      the previous block's output, formed while loading exactly as
+ *                                                       srmi_conv3x3's gated input does; stored to in_sum if given
+ *   out = conv2(relu(conv1(x') + b1)) + b2             the tensor between the two convolutions stays on the chip
+ * and, with `ca` set, the channel-attention tail of srmi_conv3x3 on `out` (pooling, squeeze / excite, sigmoid ->
+ * ca.scale).  The block's last line, out * scale * res_scale + x', is again left to the consumer's gated input.
+ * For a block whose input is a plain tensor pass in_gate = in and gate_alpha = 0 (gate must still point at finite
+ * floats).  f16 tensors, c = 64; w1 / w2 from srmi_pack_conv3x3(SRMI_F16, 64, 64, 64, 1, ...).  `out` and in_sum must not
+ * alias `in` or in_gate (other workgroups still read their halos).
+ */
+typedef struct {
+    int32_t dtype;        /* SRMI_F16 */
+    int32_t n, h, w, c;
+    float gate_alpha;
+    srmi_tensor_t in, in_gate, in_sum;
+    const float* gate;    /* float[n][c] (device) */
+    const void* w1;       /* packed weights of the first convolution (device) */
+    const float* b1;
+    const void* w2;
+    const float* b2;
+    srmi_tensor_t out;
+    struct {
+        uint64_t* sums;
+        uint32_t* count;
+        const float *w1, *b1, *w2, *b2;
+        float* scale;
+        int32_t cr;
+        int32_t reserved;
+    } ca;                 /* as srmi_conv_desc_t::ca; sums == NULL: no attention tail */
+} srmi_rcab_desc_t;
+
+int srmi_rcab_fused(const srmi_rcab_desc_t* d, void* hip_stream);
+
+/*
  * CALayer (rcan_model.py:61-76), split at its global dependency:
  *   srmi_ca_scale : mean = sum(chansum over tiles) / (h*w); z = relu(W1 mean + b1);
  *                   s = sigmoid(W2 z + b2)                      -> scale[n][c]
@@ -357,6 +391,11 @@ int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep);
  * output form it while loading (srmi_conv3x3's gated input) instead of a separate srmi_ca_apply pass over the
  * image; 0 keeps the separate pass.  Both give the same bytes. */
 int srmi_model_set_fused_attention(srmi_model_t* m, int on);
+/* RCAN, f16 compute with an f16 trunk and 64 features: 1 runs both convolutions of every block in one kernel
+ * (srmi_rcab_fused: the tensor between them never leaves the chip), 0 as two srmi_conv3x3 launches.  Needs the fused
+ * attention above.  Both forms stay within the half-precision parity bound; see srmi_model_get_fused_rcab for the default. */
+int srmi_model_set_fused_rcab(srmi_model_t* m, int on);
+int srmi_model_get_fused_rcab(const srmi_model_t* m);
 /* Internal HIP streams (1..4, default 3) over which the sweeps of one forward call are spread.
  * The lanes fork from and join the caller's stream through events, so a call is ordered on the
  * caller's stream exactly as with one lane; a call with a single sweep uses the caller's stream

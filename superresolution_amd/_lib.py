@@ -55,6 +55,17 @@ class ConvDesc(C.Structure):
                 ("ca_reserved", C.c_int32)]
 
 
+class RcabDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
+                ("gate_alpha", C.c_float),
+                ("inp", Tensor), ("in_gate", Tensor), ("in_sum", Tensor),
+                ("gate", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("out", Tensor),
+                ("ca_sums", C.c_void_p), ("ca_count", C.c_void_p), ("ca_w1", C.c_void_p), ("ca_b1", C.c_void_p),
+                ("ca_w2", C.c_void_p), ("ca_b2", C.c_void_p), ("ca_scale", C.c_void_p), ("ca_cr", C.c_int32),
+                ("ca_reserved", C.c_int32)]
+
+
 class ConvFirstDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cout", C.c_int32),
                 ("in_kind", C.c_int32), ("reserved", C.c_int32), ("inp", C.c_void_p),
@@ -74,6 +85,7 @@ EXPORTS = [
     "srmi_last_error", "srmi_device_count", "srmi_version",
     "srmi_conv3x3", "srmi_conv3x3_tiles", "srmi_pack_conv3x3_bytes", "srmi_pack_conv3x3",
     "srmi_pack_wino3x3_bytes", "srmi_pack_wino3x3", "srmi_model_set_winograd", "srmi_model_get_winograd",
+    "srmi_rcab_fused", "srmi_model_set_fused_rcab", "srmi_model_get_fused_rcab",
     "srmi_conv_first", "srmi_ca_scale", "srmi_ca_apply", "srmi_channel_sums",
     "srmi_pixel_shuffle", "srmi_nearest_up2", "srmi_nchw_to_planes", "srmi_planes_to_nchw",
     "srmi_resize_bilinear_u8",
@@ -113,6 +125,9 @@ def lib():
         L.srmi_pack_wino3x3.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.srmi_model_set_winograd.argtypes = [C.c_void_p, C.c_int]
         L.srmi_model_get_winograd.argtypes = [C.c_void_p]
+        L.srmi_rcab_fused.argtypes = [C.POINTER(RcabDesc), C.c_void_p]
+        L.srmi_model_set_fused_rcab.argtypes = [C.c_void_p, C.c_int]
+        L.srmi_model_get_fused_rcab.argtypes = [C.c_void_p]
         L.srmi_conv3x3.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
         L.srmi_conv3x3_tiles.argtypes = [C.c_int, C.c_int, C.c_int]
         L.srmi_conv_first.argtypes = [C.POINTER(ConvFirstDesc), C.c_void_p]

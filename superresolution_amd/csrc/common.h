@@ -69,6 +69,8 @@ struct ConvParams {
     TView in;
     const char* wpk;
     const float* bias;
+    const char* wpk2;     // fused block kernel: weights and bias of the second convolution
+    const float* bias2;
     const float* wscale;  // SRMI_I8: per-output-channel dequantisation scale (packed order), else null
     // gated input: the conv reads in + gate_alpha * (in_gate * gate[n][c]) and stores it to in_sum (if set)
     TView in_gate, in_sum;
@@ -98,6 +100,8 @@ int srmi_load_weight_file(const char* path, int want_arch, int device, srmi_mode
 
 // conv3x3.hip: per-device kernel attributes of every instantiation (current device)
 int srmi_conv3x3_prepare_device();
+// rcab_fused.hip: per-device kernel attribute of the fused block kernel (current device)
+int srmi_rcab_prepare_device();
 // wino3x3.hip: the Winograd F(2x2,3x3) form of the convolution (srmi_conv_desc_t::algo == SRMI_ALGO_WINOGRAD)
 int srmi_wino3x3_prepare_device();
 int srmi_wino3x3_tile_rows();

@@ -93,6 +93,7 @@ struct srmi_model {
     size_t ws_bytes = 0;
     int sweep = 1;
     bool fuse_attention = true;  // RCAN, half-precision trunk: attention output formed by the consuming conv
+    bool fuse_rcab = true;       // RCAN, f16 trunk, 64 features: both convolutions of a block in one kernel (srmi_rcab_fused)
     int mb_override = 0;
     // RRDBNet, f16: the grown channels x1..x4 of every dense block (and the weights that multiply them)
     // carry 8 significant bits; the trunk keeps full f16 precision (see srmi_model_set_growth_round8)
@@ -428,6 +429,31 @@ struct Exec {
             d.in_gate = gate->body; d.gate = gate->scale; d.gate_alpha = gate->alpha; d.in_sum = gate->sum;
         }
         return srmi_conv3x3(&d, stream);
+    }
+
+    // both convolutions of a residual channel-attention block in one launch (srmi_rcab_fused); gate == nullptr: the
+    // block's input is the plain tensor `in`
+    int rcab(const char* name1, const char* name2, const srmi_tensor_t& in, int h, int w, const Gate* gate,
+             const float* finite_floats, const srmi_tensor_t& out, const Attention& att) {
+        auto i1 = m->convs.find(std::string_view(name1));
+        auto i2 = m->convs.find(std::string_view(name2));
+        if (i1 == m->convs.end() || i2 == m->convs.end()) SRMI_FAIL("internal: convs '%s' / '%s' not uploaded", name1, name2);
+        srmi_rcab_desc_t r;
+        memset(&r, 0, sizeof(r));
+        r.dtype = m->cdt();
+        r.n = ns; r.h = h; r.w = w; r.c = i1->second.cout;
+        r.in = in;
+        if (gate) {
+            r.in_gate = gate->body; r.gate = gate->scale; r.gate_alpha = gate->alpha; r.in_sum = gate->sum;
+        } else {
+            r.in_gate = in; r.gate = finite_floats; r.gate_alpha = 0.f;
+        }
+        r.w1 = i1->second.wpk; r.b1 = i1->second.bias;
+        r.w2 = i2->second.wpk; r.b2 = i2->second.bias;
+        r.out = out;
+        r.ca.sums = att.sums; r.ca.count = att.count; r.ca.scale = att.scale; r.ca.cr = att.cr;
+        r.ca.w1 = att.w->w1; r.ca.b1 = att.w->b1; r.ca.w2 = att.w->w2; r.ca.b2 = att.w->b2;
+        return srmi_rcab_fused(&r, stream);
     }
 
     // int8 form of a dense-block conv (w8a8 mode)
@@ -797,7 +823,15 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
     Buf XR[2];
     if (split) { XR[0] = A.take(nf, h, w, TR); XR[1] = A.take(nf, h, w, TR); }
     Buf Tm = A.take(nf, h, w, T);
-    Buf Y = A.take(nf, h, w, T);
+    // A block's output x + res_scale * (y * s) is never written by a pass of its own (see below): the convolution that
+    // consumes it forms it while loading.
+    const bool fused = m->fuse_attention && (T == SRMI_F16 || T == SRMI_BF16) && nf <= 256 &&
+                       (!split || gate_rows_per_wave(m, h) == 2);
+    // ... and with an f16 trunk and 64 features both convolutions of a block run in one kernel, which reads the
+    // previous block's body while it writes its own: two body buffers
+    const bool rcab = fused && m->fuse_rcab && T == SRMI_F16 && !split && nf == 64 && !m->mb_override;
+    Buf Yb[2] = {A.take(nf, h, w, T), rcab ? A.take(nf, h, w, T) : Buf()};
+    int yk = 0;   // Yb[yk] holds the latest block body
     Buf H = A.take(nf, h, w, TR);
     Buf GI[2] = {A.take(nf, h, w, TR), A.take(nf, h, w, TR)};
     const int ns = A.ns;
@@ -807,7 +841,9 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
     uint32_t* ca_count = (uint32_t*)A.take_floats((size_t)ns);
     float* scale = A.take_floats((size_t)ns * nf);
     if (ex) {
-        SRMI_HIP(hipMemsetAsync(ca_sums, 0, (size_t)((char*)scale - (char*)ca_sums), ex->stream));
+        // (the attention scales too: a block with a plain input passes them as its gate vector with a factor of zero,
+        // which wants finite numbers)
+        SRMI_HIP(hipMemsetAsync(ca_sums, 0, (size_t)((char*)(scale + (size_t)ns * nf) - (char*)ca_sums), ex->stream));
         srmi_tensor_t o = tv(XT[0]), o2 = tv(H);
         if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
         char name[96];
@@ -815,11 +851,9 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
         int kr = 0;   // XR[kr] holds it in the trunk dtype (split mode), when trunk_in_xr
         bool trunk_in_xr = false;
         int ca_index = 0;
-        // A block's output x + res_scale * (y * s) is never written by a pass of its own: the convolution that
-        // consumes it (the next block's first, or the group's last) forms it while loading and, where a later
-        // residual needs it, stores it on the way (in the trunk's own precision: half, or f32 when split).
-        const bool fused = m->fuse_attention && (T == SRMI_F16 || T == SRMI_BF16) && nf <= 256 &&
-                           (!split || gate_rows_per_wave(m, h) == 2);
+        // (fused:) the convolution that consumes a block's output (the next block's first, or the group's last) forms
+        // it while loading and, where a later residual needs it, stores it on the way (in the trunk's own precision:
+        // half, or f32 when split).
         for (int g = 0; g < d.n_groups; ++g) {
             const Buf& Gin = g == 0 ? H : GI[g & 1];
             bool pending = false;  // trunk + res_scale * (Y * scale) is the block's output, not yet stored
@@ -827,7 +861,19 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
             auto trunk_view = [&]() { return !split ? tv(XT[k]) : (trunk_in_xr ? tv(XR[kr]) : tv(Gin)); };
             for (int b = 0; b < d.n_blocks; ++b) {
                 snprintf(name, sizeof(name), "body.%d.body.%d.body.0", g, b);
-                const srmi_tensor_t t = tv(Tm), y = tv(Y);
+                if (rcab) {
+                    char name2[96];
+                    snprintf(name2, sizeof(name2), "body.%d.body.%d.body.2", g, b);
+                    const Exec::Attention att{&m->cas[ca_index++], cr, ca_sums, ca_count, scale};
+                    const srmi_tensor_t in = trunk_view();
+                    const Exec::Gate gate{tv(Yb[yk]), scale, d.res_scale, tv(XT[k ^ 1])};
+                    if (ex->rcab(name, name2, in, h, w, pending ? &gate : nullptr, scale, tv(Yb[yk ^ 1]), att)) return -1;
+                    if (pending) k ^= 1;
+                    yk ^= 1;
+                    pending = true;
+                    continue;
+                }
+                const srmi_tensor_t t = tv(Tm), y = tv(Yb[yk]);
                 if (pending) {
                     const srmi_tensor_t in = trunk_view();
                     const Exec::Gate gate{y, scale, d.res_scale, split ? tv(XR[kr ^ 1]) : tv(XT[k ^ 1])};
@@ -861,7 +907,7 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
             const srmi_tensor_t res = tv(Gin), o1 = tv(XT[k ^ 1]), og = tv(GI[(g + 1) & 1]);
             if (pending) {
                 const srmi_tensor_t in = trunk_view();
-                const Exec::Gate gate{tv(Y), scale, d.res_scale, srmi_tensor_t{}};
+                const Exec::Gate gate{tv(Yb[yk]), scale, d.res_scale, srmi_tensor_t{}};
                 if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, &og, nullptr,
                              gate_rows_per_wave(m, h), &gate)) return -1;
             } else {
@@ -1354,7 +1400,7 @@ extern "C" int srmi_model_finalize(srmi_model_t* m) {
     // set-up for the allocation-free entry point: this device's address of the static workspace, and
     // the per-device kernel attributes, so that nothing but launches is left for the call itself
     if (static_workspace(d.device, &m->static_ws)) return -1;
-    if (srmi_conv3x3_prepare_device()) return -1;
+    if (srmi_conv3x3_prepare_device() || srmi_rcab_prepare_device()) return -1;
     m->finalized = true;
     return 0;
 }
@@ -1454,6 +1500,15 @@ extern "C" int srmi_model_set_fused_attention(srmi_model_t* m, int on) {
     m->fuse_attention = on != 0;
     return 0;
 }
+
+extern "C" int srmi_model_set_fused_rcab(srmi_model_t* m, int on) {
+    if (!m) SRMI_FAIL("srmi_model_set_fused_rcab: null model");
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    m->fuse_rcab = on != 0;
+    return 0;
+}
+
+extern "C" int srmi_model_get_fused_rcab(const srmi_model_t* m) { return (m && m->fuse_rcab) ? 1 : 0; }
 
 extern "C" int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep) {
     if (!m || images_per_sweep < 1) SRMI_FAIL("srmi_model_set_sweep: bad argument");

@@ -83,6 +83,14 @@ class Engine:
         while loading (default) or a separate elementwise pass does; the results are the same bytes."""
         check(lib().srmi_model_set_fused_attention(self._h, int(bool(on))), "srmi_model_set_fused_attention")
 
+    def set_fused_rcab(self, on=True):
+        """RCAN, f16 with an f16 trunk and 64 features: both convolutions of a block in one kernel (True) or as two
+        launches (False)."""
+        check(lib().srmi_model_set_fused_rcab(self._h, int(bool(on))), "srmi_model_set_fused_rcab")
+
+    def fused_rcab(self):
+        return bool(lib().srmi_model_get_fused_rcab(self._h))
+
     def set_winograd(self, on=True):
         """RRDBNet, f16 compute: run the dense blocks' convolutions in their Winograd F(2x2,3x3) form (True) or in the
         direct form (False); takes effect at the next forward."""

@@ -201,6 +201,47 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
     return result
 
 
+def rcab_fused(x: Planes, pc1: PackedConv, pc2: PackedConv, *, in_gate: Planes = None, gate: torch.Tensor = None,
+               gate_alpha=1.0, in_sum: Planes = None, attention=None):
+    """conv2(relu(conv1(x'))) in one launch, x' = x + gate_alpha * (in_gate * gate[n][c]) (srmi_rcab_fused).  Without
+    in_gate the block's input is x itself.  attention: (w1, b1, w2, b2) of the CALayer -> also returns scale[n][c]."""
+    n, c, h, w = x.n, x.c, x.h, x.w
+    d = _lib.RcabDesc()
+    d.dtype, d.n, d.h, d.w, d.c = x.dtype, n, h, w, c
+    d.inp = x.view()
+    keep = [x, pc1, pc2, in_gate, gate, in_sum]
+    if in_gate is not None:
+        d.in_gate, d.gate, d.gate_alpha = in_gate.view(), gate.data_ptr(), gate_alpha
+        d.in_sum = in_sum.view() if in_sum is not None else _NULL
+    else:
+        zeros = torch.zeros((n, c), dtype=torch.float32, device="cuda")
+        keep.append(zeros)
+        d.in_gate, d.gate, d.gate_alpha = x.view(), zeros.data_ptr(), 0.0
+    d.w1, d.b1, d.w2, d.b2 = pc1.w.data_ptr(), pc1.b.data_ptr(), pc2.w.data_ptr(), pc2.b.data_ptr()
+    out = Planes(n, c, h, w, x.dtype)
+    d.out = out.view()
+    att_scale = None
+    if attention is not None:
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1))).cuda()
+        w1, b1, w2, b2 = (dev(a) for a in attention)
+        att_sums = torch.zeros((n, _lib.CA_SLOTS, c), dtype=torch.int64, device="cuda")
+        att_count = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        att_scale = torch.empty((n, c), dtype=torch.float32, device="cuda")
+        d.ca_sums, d.ca_count, d.ca_scale = att_sums.data_ptr(), att_count.data_ptr(), att_scale.data_ptr()
+        d.ca_w1, d.ca_b1, d.ca_w2, d.ca_b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+        d.ca_cr = b1.numel()
+        keep += [w1, b1, w2, b2, att_sums, att_count]
+    check(lib().srmi_rcab_fused(C.byref(d), _stream()), "rcab_fused")
+    torch.cuda.current_stream().synchronize()
+    if attention is not None:
+        if int(att_sums.abs().max()) or int(att_count.abs().max()):
+            raise _lib.SrmiError("rcab_fused: attention accumulators were not left at zero")
+        del keep
+        return out, att_scale
+    del keep
+    return out
+
+
 def conv_first(inp: torch.Tensor, weight, bias, dtype, *, pre_mat=None, pre_bias=None, out2_dtype=None):
     """First (3-channel) layer; inp is f32 NCHW or u8 NHWC on the GPU."""
     w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))  # [cout][3][3][3] OIHW
