@@ -181,7 +181,19 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(TView x, long long hw
     const long long p_end = p_begin + seg < hw ? p_begin + seg : hw;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ch < c) {
-        for (long long pix = p_begin + (threadIdx.x >> 1); pix < p_end; pix += 128) {
+        // four independent 16-byte loads in flight per thread (the sum is over f32 values of a fixed set per thread,
+        // added in a fixed order: reproducible)
+        long long pix = p_begin + (threadIdx.x >> 1);
+        for (; pix + 384 < p_end; pix += 512) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8(x, n, pix + 128 * u, ch, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[u][j];
+        }
+        for (; pix < p_end; pix += 128) {
             float v[8];
             load8(x, n, pix, ch, v);
 #pragma unroll
@@ -272,21 +284,61 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(TView in, TView out,
     }
 }
 
+// PixelShuffle(2) on 2-byte elements with 16-byte accesses only: one thread = one INPUT pixel x 64 input channels (four
+// planes = eight 16-byte chunks) = one whole 16-channel output plane of the four output pixels (2y + i, 2x + j): input
+// channel 4 * co + (2 i + j) -> output channel co (edsr_model.py:57; rcan_model.py:44).  The halves are regrouped in
+// registers; a thread writes 64 contiguous bytes per output row, so the stores of a wave cover whole cache lines.
+__global__ __launch_bounds__(256) void pixel_shuffle2_h16_kernel(TView in, TView out, int n_img, int h, int w, int c_out) {
+    const int oplanes = c_out >> 4;
+    const long long hw = (long long)h * w;
+    const long long total = (long long)n_img * oplanes * hw;
+    const int ow = 2 * w;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long pix = idx % hw;
+        long long t = idx / hw;
+        const int g = (int)(t % oplanes);
+        const int n = (int)(t / oplanes);
+        const int y = (int)(pix / w), x = (int)(pix - (long long)y * w);
+        const char* ib = in.ptr + (long long)n * in.img_stride_b + (long long)(4 * g) * in.plane_stride_b + pix * kPixBytes;
+        unsigned short v[64];
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            *(u32x4*)(v + 16 * pl) = *(const u32x4*)(ib + (long long)pl * in.plane_stride_b);
+            *(u32x4*)(v + 16 * pl + 8) = *(const u32x4*)(ib + (long long)pl * in.plane_stride_b + 16);
+        }
+        char* ob = out.ptr + (long long)n * out.img_stride_b + (long long)g * out.plane_stride_b;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            __attribute__((aligned(16))) unsigned short o[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = v[4 * e + ij];
+            char* d = ob + ((long long)(2 * y + (ij >> 1)) * ow + 2 * x + (ij & 1)) * kPixBytes;
+            *(u32x4*)d = *(const u32x4*)o;
+            *(u32x4*)(d + 16) = *(const u32x4*)(o + 8);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nearest_up2_kernel(TView in, TView out, int n_img, int h, int w, int planes) {
-    const int oh = 2 * h, ow = 2 * w;
-    const long long total = (long long)n_img * planes * oh * ow * 2;  // two 16-byte chunks per pixel of a plane
+    // one thread = one 16-byte chunk of an input pixel -> the same chunk of its four output pixels: every input byte is
+    // read once (the previous form read it four times, through the cache)
+    const int ow = 2 * w;
+    const long long total = (long long)n_img * planes * h * w * 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int ck = (int)(idx & 1);
         long long t = idx >> 1;
-        const int ox = (int)(t % ow); t /= ow;
-        const int oy = (int)(t % oh); t /= oh;
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h); t /= h;
         const int pl = (int)(t % planes);
         const int n = (int)(t / planes);
-        const char* s = in.ptr + (long long)n * in.img_stride_b + (long long)pl * in.plane_stride_b +
-                        ((long long)(oy >> 1) * w + (ox >> 1)) * kPixBytes + ck * 16;
+        const u32x4 v = *(const u32x4*)(in.ptr + (long long)n * in.img_stride_b + (long long)pl * in.plane_stride_b +
+                                        ((long long)y * w + x) * kPixBytes + ck * 16);
         char* d = out.ptr + (long long)n * out.img_stride_b + (long long)pl * out.plane_stride_b +
-                  ((long long)oy * ow + ox) * kPixBytes + ck * 16;
-        *(u32x4*)d = *(const u32x4*)s;
+                  ((long long)(2 * y) * ow + 2 * x) * kPixBytes + ck * 16;
+        *(u32x4*)d = v;
+        *(u32x4*)(d + kPixBytes) = v;
+        *(u32x4*)(d + (long long)ow * kPixBytes) = v;
+        *(u32x4*)(d + (long long)ow * kPixBytes + kPixBytes) = v;
     }
 }
 
@@ -406,7 +458,7 @@ extern "C" int srmi_ca_apply(const srmi_tensor_t* y, const srmi_tensor_t* x, con
     o2.ptr = nullptr; o2.img_stride_b = o2.plane_stride_b = 0; o2.dtype = 0; o2.flags = 0;
     if (out2) o2 = to_view(*out2);
     const long long hw = (long long)h * w;
-    hipLaunchKernelGGL(ca_apply_kernel, dim3(grid_for(n * hw * (c / 8))), dim3(256), 0, (hipStream_t)hip_stream,
+    hipLaunchKernelGGL(ca_apply_kernel, dim3(grid_for(n * hw * (c / 8), 256, 1 << 20)), dim3(256), 0, (hipStream_t)hip_stream,
                        to_view(*y), to_view(*x), scale, res_scale, n, hw, c, to_view(*out), o2);
     SRMI_HIP(hipGetLastError());
     return 0;
@@ -449,7 +501,10 @@ extern "C" int srmi_pixel_shuffle(const srmi_tensor_t* in, const srmi_tensor_t* 
     if (c_out % epc) SRMI_FAIL("srmi_pixel_shuffle: c_out=%d is not a multiple of %d", c_out, epc);
     const long long total = (long long)n * h * r * w * r * (c_out / epc);
     hipStream_t s = (hipStream_t)hip_stream;
-    if (in->dtype == SRMI_F32)
+    if (in->dtype != SRMI_F32 && r == 2 && c_out % 16 == 0)
+        hipLaunchKernelGGL(pixel_shuffle2_h16_kernel, dim3(grid_for((long long)n * (c_out / 16) * h * w, 256, 1 << 20)), dim3(256), 0, s,
+                           to_view(*in), to_view(*out), n, h, w, c_out);
+    else if (in->dtype == SRMI_F32)
         hipLaunchKernelGGL(pixel_shuffle_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, to_view(*in), to_view(*out), n, h, w, c_out, r);
     else
         hipLaunchKernelGGL(pixel_shuffle_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, s, to_view(*in), to_view(*out), n, h, w, c_out, r);
@@ -464,8 +519,8 @@ extern "C" int srmi_nearest_up2(const srmi_tensor_t* in, const srmi_tensor_t* ou
     const int cpb = dtype_cpb(in->dtype);
     if (c <= 0 || c % cpb) SRMI_FAIL("srmi_nearest_up2: c=%d is not a multiple of %d", c, cpb);
     const int planes = c / cpb;
-    const long long total = (long long)n * planes * h * 2 * w * 2 * 2;
-    hipLaunchKernelGGL(nearest_up2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)hip_stream,
+    const long long total = (long long)n * planes * h * w * 2;
+    hipLaunchKernelGGL(nearest_up2_kernel, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, (hipStream_t)hip_stream,
                        to_view(*in), to_view(*out), n, h, w, planes);
     SRMI_HIP(hipGetLastError());
     return 0;

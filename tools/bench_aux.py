@@ -1,18 +1,20 @@
-"""HBM-bound kernels at the bench sizes (510x339, 64 channels, f16).  Run under rocprofv3 --kernel-trace --stats;
+"""HBM-bound kernels at the bench sizes (510x339 by default, 64 channels, f16).  Run under rocprofv3 --kernel-trace --stats;
 `--report <kernel_stats.csv>` joins the measured average durations with the algorithmic bytes below and prints the
 achieved GB/s against the 8 TB/s HBM peak."""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-H, W, C = 339, 510, 64
+# frame size: SRMI_AUX_SIZE=WxH in the environment (default the bench frame 510x339; 1920x1080 is the large-frame case)
+W, H = (int(v) for v in os.environ.get("SRMI_AUX_SIZE", "510x339").split("x"))
+C = 64
 PX = H * W
 # algorithmic bytes per launch (each tensor read or written once)
 BYTES = {
     "conv_first_kernel": PX * 3 + PX * C * 2,
     "ca_apply_kernel": 3 * PX * C * 2,
-    "ca_scale_kernel": 464 * C * 4,
+    "ca_scale_kernel": ((H + 11) // 12) * ((W + 31) // 32) * C * 4,
     "channel_sums_kernel": PX * C * 2,
-    "pixel_shuffle_kernel": 2 * PX * 4 * C * 2,
+    "pixel_shuffle": 2 * PX * 4 * C * 2,
     "nearest_up2_kernel": PX * C * 2 + 4 * PX * C * 2,
     "nchw_to_planes_kernel": PX * C * 4 + PX * C * 2,
     "planes_to_nchw_kernel": PX * C * 2 + PX * C * 4,
@@ -40,7 +42,8 @@ b0 = np.zeros(C, np.float32)
 x = ops.Planes(1, C, H, W, dt); x.buf.normal_()
 y = ops.Planes(1, C, H, W, dt); y.buf.normal_()
 x4 = ops.Planes(1, 4 * C, H, W, dt); x4.buf.normal_()
-sums = torch.randn(1, 464, C, device="cuda")
+TILES = ((H + 11) // 12) * ((W + 31) // 32)
+sums = torch.randn(1, TILES, C, device="cuda")
 w1, b1 = synth.hash_uniform("w1", (4, C), 2), np.zeros(4, np.float32)
 w2, b2 = synth.hash_uniform("w2", (C, 4), 3), np.zeros(C, np.float32)
 scale = torch.rand(1, C, device="cuda")
