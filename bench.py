@@ -361,9 +361,9 @@ def main():
                     help="RCAN: separate elementwise pass per channel-attention block instead of the gated conv input")
     ap.add_argument("--no-fused-rcab", action="store_true",
                     help="RCAN: the two convolutions of a block as two launches instead of one kernel")
-    ap.add_argument("--winograd", action="store_true",
-                    help="RRDBNet f16: the dense blocks' convolutions in their Winograd F(2x2,3x3) form (slower on whole "
-                         "layers; kept for A/B runs)")
+    ap.add_argument("--winograd", type=int, default=None, choices=[0, 1, 2],
+                    help="RRDBNet f16: the dense blocks' convolutions in the direct form (0), the Winograd F(2x2,3x3) form (1) "
+                         "or the Winograd F(2,3)-along-x form (2); default: the library's choice")
     ap.add_argument("--w8a8", action="store_true",
                     help="RRDBNet: calibrate on synthetic frames and run the dense blocks in int8 (a lower-precision "
                          "configuration of its own; never the headline)")
@@ -432,8 +432,8 @@ def main():
             engs[-1].set_fused_attention(False)
         if args.no_fused_rcab:
             engs[-1].set_fused_rcab(False)
-        if args.winograd:
-            engs[-1].set_winograd(True)
+        if args.winograd is not None:
+            engs[-1].set_winograd(args.winograd)
         engs[-1].set_lanes(args.lanes)
         if args.w8a8:
             engs[-1].calibrate(np.stack([synth.smooth_image(h, w, 900 + i) for i in range(4)] +

@@ -82,7 +82,8 @@ typedef struct {
  * grown channels x1..x4 of a dense block, realesrgan_model.py:27-30) are kept that way. */
 #define SRMI_TENSOR_ROUND8 1
 #define SRMI_ALGO_DIRECT 0
-#define SRMI_ALGO_WINOGRAD 1
+#define SRMI_ALGO_WINOGRAD 1     /* F(2x2,3x3) */
+#define SRMI_ALGO_WINOGRAD_X 2   /* F(2,3) along x */
 #define SRMI_CA_SLOTS 8   /* accumulators per image and channel of srmi_conv_desc_t::ca */
 
 /*
@@ -152,7 +153,9 @@ typedef struct {
      * convolution with 16 instead of 36 multiplies per 2x2 output tile and input channel; f16 compute only, weights
      * from srmi_pack_wino3x3, cin a multiple of 32, cout_tile 32, no in_up2 / gated input / pixel shuffle / tail / channel attention.  The
      * input transform adds and the transformed weights are rounded to f16, so results differ from the direct form in
-     * the last bits (both stay within the half-precision parity bound of the networks). */
+     * the last bits (both stay within the half-precision parity bound of the networks).
+     * SRMI_ALGO_WINOGRAD_X: Winograd F(2,3) along x only (4 instead of 6 multiplies per pair of output pixels and
+     * vertical tap, weights from srmi_pack_wino1d3x3), same restrictions. */
     int32_t algo;
     srmi_tensor_t in_sum;
     /* Channel attention finished inside the convolution (CALayer, rcan_model.py:61-76): with ca.sums set, every
@@ -190,6 +193,10 @@ int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, int ps_r,
  * cin a multiple of 16, cout a multiple of 32 (padded rows are zero).  Bias as in srmi_pack_conv3x3 (cout_tile 32). */
 size_t srmi_pack_wino3x3_bytes(int cout, int cin, int* bias_floats);
 int srmi_pack_wino3x3(int cout, int cin, const float* w_oihw, const float* bias, void* wpk_out, float* bias_out);
+/* The same for SRMI_ALGO_WINOGRAD_X: U[ky][xi] = sum_kx G[xi][kx] g[ky][kx], laid out
+ * [cout tile of 32][stage of 16 input channels][vertical tap 3][position 4][channel half 2][output 32][8 halves]. */
+size_t srmi_pack_wino1d3x3_bytes(int cout, int cin, int* bias_floats);
+int srmi_pack_wino1d3x3(int cout, int cin, const float* w_oihw, const float* bias, void* wpk_out, float* bias_out);
 
 /*
  * First layer: 3-channel input -> cout channels.  Fuses the network's pre-processing
@@ -409,8 +416,9 @@ int srmi_model_set_lanes(srmi_model_t* m, int lanes);
  * result stays within the half-precision parity bound (u8 diff <= 1 LSB, PSNR >= 50 dB); 0 gives
  * plain f16 everywhere. */
 int srmi_model_set_growth_round8(srmi_model_t* m, int on);
-/* RRDBNet with f16 compute: 1 runs the 15 convolutions of every RRDB (realesrgan_model.py:13-49) in their Winograd
- * F(2x2,3x3) form (SRMI_ALGO_WINOGRAD), 0 (default) in the direct form.  Takes effect at the next forward call; both
+/* RRDBNet with f16 compute: `on` = SRMI_ALGO_WINOGRAD (1) runs the 15 convolutions of every RRDB
+ * (realesrgan_model.py:13-49) in their Winograd F(2x2,3x3) form, SRMI_ALGO_WINOGRAD_X (2) in the F(2,3)-along-x form,
+ * 0 in the direct form; srmi_model_get_winograd returns the current choice (the library's default included).  Takes effect at the next forward call; both
  * forms of the weights are packed at srmi_model_finalize.  Frames of 8 rows or fewer always run the direct form.
  * Both forms meet the half-precision parity bound; the direct form is the faster one on whole layers. */
 int srmi_model_set_winograd(srmi_model_t* m, int on);

@@ -106,3 +106,7 @@ int srmi_rcab_prepare_device();
 int srmi_wino3x3_prepare_device();
 int srmi_wino3x3_tile_rows();
 int srmi_wino3x3_launch(const srmi::ConvParams& p, hipStream_t stream);
+// wino1d3x3.hip: the Winograd F(2,3)-along-x form (algo == SRMI_ALGO_WINOGRAD_X)
+int srmi_wino1d3x3_prepare_device();
+void srmi_wino1d3x3_tile(int* rows, int* cols);
+int srmi_wino1d3x3_launch(const srmi::ConvParams& p, hipStream_t stream);

@@ -787,7 +787,7 @@ using namespace srmi;
 // (for instance under stream capture) consist of the launch alone.
 int srmi_conv3x3_prepare_device() {
     return (configure_dt<SRMI_F16>() || configure_dt<SRMI_BF16>() || configure_dt<SRMI_F32>() || configure_dt<SRMI_I8>() ||
-            srmi_wino3x3_prepare_device()) ? -1 : 0;
+            srmi_wino3x3_prepare_device() || srmi_wino1d3x3_prepare_device()) ? -1 : 0;
 }
 
 extern "C" int srmi_conv3x3_tiles(int h, int w, int rows_per_wave) {
@@ -813,7 +813,8 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     if (!d->in.ptr || (d->in.dtype != d->dtype && !gated_f32)) SRMI_FAIL("srmi_conv3x3: input tensor missing or of another dtype");
     if (!d->wpk || !d->bias) SRMI_FAIL("srmi_conv3x3: missing weights or bias");
     if (d->cout_tile != 32 && d->cout_tile != 64) SRMI_FAIL("srmi_conv3x3: cout_tile must be 32 or 64");
-    const bool wino = d->algo == SRMI_ALGO_WINOGRAD;
+    const bool wino_x = d->algo == SRMI_ALGO_WINOGRAD_X;
+    const bool wino = d->algo == SRMI_ALGO_WINOGRAD || wino_x;
     if (d->algo != SRMI_ALGO_DIRECT && !wino) SRMI_FAIL("srmi_conv3x3: unknown algo %d", d->algo);
     if (wino) {
         if (d->dtype != SRMI_F16) SRMI_FAIL("srmi_conv3x3: the Winograd form computes in f16 only");
@@ -823,7 +824,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
                       "channel sums and channel attention");
     }
     // the Winograd kernel has one tile shape: 16 rows (4 per wave)
-    const int mb = wino ? srmi_wino3x3_tile_rows() / kNW : (d->rows_per_wave ? d->rows_per_wave : default_rows_per_wave());
+    const int mb = wino_x ? 2 : wino ? srmi_wino3x3_tile_rows() / kNW : (d->rows_per_wave ? d->rows_per_wave : default_rows_per_wave());
     if (mb < 2 || mb > 4) SRMI_FAIL("srmi_conv3x3: rows_per_wave must be 2, 3 or 4");
     if (d->cout_tile == 64 && mb == 4) SRMI_FAIL("srmi_conv3x3: rows_per_wave 4 needs cout_tile 32");
     const bool tail = d->tail_mode != SRMI_TAIL_NONE;
@@ -908,6 +909,13 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     p.tail_lo = d->tail_lo; p.tail_hi = d->tail_hi; p.tail_scale = d->tail_scale;
 
     hipStream_t s = (hipStream_t)hip_stream;
+    if (wino_x) {
+        int th = 0, tw = 0;
+        srmi_wino1d3x3_tile(&th, &tw);
+        p.tiles_x = (d->w + tw - 1) / tw;
+        p.tiles_y = (d->h + th - 1) / th;
+        return srmi_wino1d3x3_launch(p, s);
+    }
     if (wino) return srmi_wino3x3_launch(p, s);
     const int nb = d->cout_tile / 32;
     if (d->dtype == SRMI_F16) return launch_dt<SRMI_F16>(p, mb, nb, s);

@@ -103,20 +103,25 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 
 // After the half-wave exchange a lane owns, for its pixel, the 8 consecutive channels
 // 16*q + 8*lh .. +7 of every 32-channel block (q = 0, 1): all tensor accesses are 16 or 32 bytes.
-// WINO: the accumulators come out of the Winograd kernel's output transform: "row" r of a lane is pixel
-// (r >> 1, r & 1) of its 2x2 output tile, the wave's 32 tiles lie as 2 tile rows x 16 tile columns (MB == 4).
-template <int DT, int MB, int NB, int OUT, int RES, bool RES2, int OUT2, bool WINO = false>
+// WINO != 0: the accumulators come out of a Winograd kernel's output transform (MB == 4 pixels per lane).
+//   1 (F(2x2,3x3)): "row" r of a lane is pixel (r >> 1, r & 1) of its 2x2 output tile; the wave's 32 tiles lie as 2 tile
+//     rows x 16 tile columns;
+//   2 (F(2,3) along x): "row" r is pixel (row r >> 1, column r & 1) of the lane's pair of two-pixel tiles in the wave's
+//     two image rows; the wave's 32 tile columns span 64 pixels.
+template <int DT, int MB, int NB, int OUT, int RES, bool RES2, int OUT2, int WINO = 0>
 __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f32x16 (&acc)[MB][NB],
                                          const float* lds_bias, float* lds_red) {
     constexpr bool generic = OUT == kAnyType;
     static_assert(!WINO || MB == 4, "a 2x2 output tile has four pixels");
     // image coordinates of accumulator row r of this lane
     auto row_y = [&](const int r) {
-        if constexpr (WINO) return k.y0 + k.wave * 4 + 2 * (k.lx >> 4) + (r >> 1);
+        if constexpr (WINO == 1) return k.y0 + k.wave * 4 + 2 * (k.lx >> 4) + (r >> 1);
+        else if constexpr (WINO == 2) return k.y0 + k.wave * 2 + (r >> 1);
         else return k.y0 + k.wave * MB + r;
     };
     auto row_x = [&](const int r) {
-        if constexpr (WINO) return k.x0 + 2 * (k.lx & 15) + (r & 1);
+        if constexpr (WINO == 1) return k.x0 + 2 * (k.lx & 15) + (r & 1);
+        else if constexpr (WINO == 2) return k.x0 + 2 * k.lx + (r & 1);
         else return k.x0 + k.lx;
     };
     const bool tail = generic && p.tail_mode != SRMI_TAIL_NONE;

@@ -48,6 +48,7 @@ struct HostTensor {
 
 struct ConvW {
     void* wpk_wino = nullptr;  // Winograd F(2x2,3x3) form of the same weights (RRDBNet dense blocks, f16), else null
+    void* wpk_wino_x = nullptr;  // Winograd F(2,3)-along-x form
     void* wpk = nullptr;
     float* bias = nullptr;
     float* wscale = nullptr;  // int8 convs: per-output-channel dequantisation scale
@@ -101,7 +102,7 @@ struct srmi_model {
     // RRDBNet, f16: the dense blocks' convolutions run in their Winograd F(2x2,3x3) form (srmi_model_set_winograd).
     // Off by default: measured slower than the direct form on whole layers (its 256 accumulator registers allow one
     // wave per SIMD, so nothing on the CU hides a workgroup's first loads and its epilogue).
-    bool winograd = false;
+    int winograd = SRMI_ALGO_DIRECT;   // SRMI_ALGO_* of the dense blocks' convolutions
 
     // Independent sweeps of one call run on `lanes` internal streams that fork from and join the
     // caller's stream, so that one sweep's launch gaps, prologues and epilogues overlap another's
@@ -302,6 +303,13 @@ static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
             if (srmi_pack_wino3x3(cw.cout, cw.cin, w.data.data(), b.data.data(), up.data(), b2.data())) return -1;
             if (dev_upload(m, up.data(), wb, &cw.wpk_wino)) return -1;
         }
+        const size_t xb = srmi_pack_wino1d3x3_bytes(cw.cout, cw.cin, &nb2);
+        if (xb && nb2 == nbias) {
+            std::vector<char> up(xb);
+            std::vector<float> b2(nb2);
+            if (srmi_pack_wino1d3x3(cw.cout, cw.cin, w.data.data(), b.data.data(), up.data(), b2.data())) return -1;
+            if (dev_upload(m, up.data(), xb, &cw.wpk_wino_x)) return -1;
+        }
     }
     m->convs[name] = cw;
     return 0;
@@ -410,9 +418,10 @@ struct Exec {
         d.in = in;
         d.wpk = cw.wpk; d.bias = cw.bias;
         // Winograd form where it exists and applies (not while calibrating: the recorded ranges belong to the direct form)
-        if (m->winograd && cw.wpk_wino && !up2 && !gate && !att && !chansum && h > 8 && !m->calibrating) {
-            d.algo = SRMI_ALGO_WINOGRAD;
-            d.wpk = cw.wpk_wino;
+        void* const wino_w = m->winograd == SRMI_ALGO_WINOGRAD ? cw.wpk_wino : m->winograd == SRMI_ALGO_WINOGRAD_X ? cw.wpk_wino_x : nullptr;
+        if (wino_w && !up2 && !gate && !att && !chansum && h > 8 && !m->calibrating) {
+            d.algo = m->winograd;
+            d.wpk = wino_w;
             d.rows_per_wave = 0;
         }
         d.alpha = alpha; d.beta = beta;
@@ -1526,11 +1535,13 @@ extern "C" int srmi_model_set_growth_round8(srmi_model_t* m, int on) {
 extern "C" int srmi_model_set_winograd(srmi_model_t* m, int on) {
     if (!m) SRMI_FAIL("srmi_model_set_winograd: null model");
     std::lock_guard<std::mutex> lock(m->call_mutex);
-    m->winograd = on != 0;
+    if (on != SRMI_ALGO_DIRECT && on != SRMI_ALGO_WINOGRAD && on != SRMI_ALGO_WINOGRAD_X)
+        SRMI_FAIL("srmi_model_set_winograd: %d is none of SRMI_ALGO_DIRECT / _WINOGRAD / _WINOGRAD_X", on);
+    m->winograd = on;
     return 0;
 }
 
-extern "C" int srmi_model_get_winograd(const srmi_model_t* m) { return (m && m->winograd) ? 1 : 0; }
+extern "C" int srmi_model_get_winograd(const srmi_model_t* m) { return m ? m->winograd : 0; }
 
 extern "C" int srmi_model_calibrate_begin(srmi_model_t* m) {
     if (!m) SRMI_FAIL("srmi_model_calibrate_begin: null model");

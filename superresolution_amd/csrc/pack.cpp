@@ -160,3 +160,38 @@ extern "C" int srmi_pack_wino3x3(int cout, int cin, const float* w, const float*
     for (int q = 0; q < nbias; ++q) bias_out[q] = (q < cout && bias) ? bias[q] : 0.f;
     return 0;
 }
+
+// Winograd F(2,3) along x: U[ky][xi] = sum_kx G[xi][kx] g[ky][kx] per (output, input) channel pair.
+extern "C" size_t srmi_pack_wino1d3x3_bytes(int cout, int cin, int* bias_floats) {
+    if (cin <= 0 || cin % 16 || cout <= 0) return 0;
+    const int ntile = (cout + 31) / 32;
+    if (bias_floats) *bias_floats = ntile * 32;
+    return (size_t)ntile * (cin / 16) * 12 * 32 * kPixBytes;
+}
+
+extern "C" int srmi_pack_wino1d3x3(int cout, int cin, const float* w, const float* bias, void* wpk_out, float* bias_out) {
+    int nbias = 0;
+    const size_t bytes = srmi_pack_wino1d3x3_bytes(cout, cin, &nbias);
+    if (!bytes) SRMI_FAIL("srmi_pack_wino1d3x3: bad shape cout=%d cin=%d (cin must be a multiple of 16)", cout, cin);
+    if (!w || !wpk_out || !bias_out) SRMI_FAIL("srmi_pack_wino1d3x3: null pointer");
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nstage = cin / 16, ntile = nbias / 32;
+    char* out = (char*)wpk_out;
+    for (int t = 0; t < ntile; ++t)
+        for (int row = 0; row < 32; ++row) {
+            const int o = t * 32 + row;
+            for (int ci = 0; ci < cin; ++ci) {
+                const float* g = w + ((size_t)(o < cout ? o : 0) * cin + ci) * 9;   // g[ky][kx]
+                const int st = ci / 16, c = (ci % 16) / 8, e = ci % 8;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int xi = 0; xi < 4; ++xi) {
+                        const double u = o < cout ? G[xi][0] * g[ky * 3 + 0] + G[xi][1] * g[ky * 3 + 1] + G[xi][2] * g[ky * 3 + 2] : 0.0;
+                        char* dst = out + ((((size_t)t * nstage + st) * 12 + ky * 4 + xi) * 2 + c) * 512 + row * 16 + e * 2;
+                        const uint16_t hv = f32_to_f16((float)u);
+                        memcpy(dst, &hv, 2);
+                    }
+            }
+        }
+    for (int q = 0; q < nbias; ++q) bias_out[q] = (q < cout && bias) ? bias[q] : 0.f;
+    return 0;
+}

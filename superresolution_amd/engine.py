@@ -92,12 +92,13 @@ class Engine:
         return bool(lib().srmi_model_get_fused_rcab(self._h))
 
     def set_winograd(self, on=True):
-        """RRDBNet, f16 compute: run the dense blocks' convolutions in their Winograd F(2x2,3x3) form (True) or in the
-        direct form (False); takes effect at the next forward."""
-        check(lib().srmi_model_set_winograd(self._h, int(bool(on))), "srmi_model_set_winograd")
+        """RRDBNet, f16 compute: run the dense blocks' convolutions in the direct form (False / 0), the Winograd
+        F(2x2,3x3) form (True / 1) or the Winograd F(2,3)-along-x form (2); takes effect at the next forward."""
+        check(lib().srmi_model_set_winograd(self._h, int(on)), "srmi_model_set_winograd")
 
     def winograd(self):
-        return bool(lib().srmi_model_get_winograd(self._h))
+        """0 direct, 1 F(2x2,3x3), 2 F(2,3) along x."""
+        return int(lib().srmi_model_get_winograd(self._h))
 
     def set_sweep(self, images_per_sweep):
         check(lib().srmi_model_set_sweep(self._h, int(images_per_sweep)), "srmi_model_set_sweep")

@@ -84,13 +84,15 @@ class PackedConv:
         if cout_tile is None:
             cout_tile = 32 if (cout <= 32 or winograd) else 64
         self.cout, self.cin, self.dtype, self.cout_tile, self.ps_r = cout, cin, dtype, cout_tile, ps_r
-        self.algo = _lib.ALGO_WINOGRAD if winograd else _lib.ALGO_DIRECT
+        # winograd: False / 0 (direct), True / 1 (F(2x2,3x3)), 2 (F(2,3) along x)
+        self.algo = int(winograd)
         nb = C.c_int(0)
         b = None if bias is None else np.ascontiguousarray(np.asarray(bias, dtype=np.float32))
         if winograd:
             if dtype != F16 or cout_tile != 32 or ps_r != 1:
                 raise _lib.SrmiError("the Winograd form needs f16, cout_tile 32 and no pixel shuffle")
-            nbytes = lib().srmi_pack_wino3x3_bytes(cout, cin, C.byref(nb))
+            nbytes = (lib().srmi_pack_wino1d3x3_bytes if self.algo == _lib.ALGO_WINOGRAD_X else
+                      lib().srmi_pack_wino3x3_bytes)(cout, cin, C.byref(nb))
         else:
             nbytes = lib().srmi_pack_conv3x3_bytes(dtype, cout, cin, cout_tile, C.byref(nb))
         if nbytes == 0:
@@ -98,8 +100,9 @@ class PackedConv:
         wp = np.empty(nbytes, dtype=np.uint8)
         bp = np.empty(nb.value, dtype=np.float32)
         if winograd:
-            check(lib().srmi_pack_wino3x3(cout, cin, w.ctypes.data, None if b is None else b.ctypes.data,
-                                          wp.ctypes.data, bp.ctypes.data), "pack_wino3x3")
+            pack = lib().srmi_pack_wino1d3x3 if self.algo == _lib.ALGO_WINOGRAD_X else lib().srmi_pack_wino3x3
+            check(pack(cout, cin, w.ctypes.data, None if b is None else b.ctypes.data, wp.ctypes.data, bp.ctypes.data),
+                  "pack_wino3x3")
         else:
             check(lib().srmi_pack_conv3x3(dtype, cout, cin, cout_tile, ps_r, w.ctypes.data,
                                           None if b is None else b.ctypes.data, wp.ctypes.data, bp.ctypes.data),

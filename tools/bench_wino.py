@@ -32,10 +32,12 @@ def bench(cin, cout, h, w, winograd, iters=60):
 if __name__ == "__main__":
     h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (339, 510)
     print(f"frame {w}x{h}, one launch at a time (one stream)")
-    tot = [0.0, 0.0]
+    tot = [0.0, 0.0, 0.0]
     for cin, cout in ((64, 32), (96, 32), (128, 32), (160, 32), (192, 64)):
-        a, b = bench(cin, cout, h, w, False), bench(cin, cout, h, w, True)
+        a, b, c = bench(cin, cout, h, w, 0), bench(cin, cout, h, w, 1), bench(cin, cout, h, w, 2)
         tot[0] += a[0]
         tot[1] += b[0]
-        print(f"cin {cin:3d} cout {cout:2d} | direct {a[0]:6.1f} us {a[1]:5.0f} TF | winograd {b[0]:6.1f} us {b[1]:5.0f} TF (algorithmic) | x{a[0] / b[0]:.2f}")
-    print(f"dense block: direct {tot[0]:.1f} us, winograd {tot[1]:.1f} us, x{tot[0] / tot[1]:.2f}")
+        tot[2] += c[0]
+        print(f"cin {cin:3d} cout {cout:2d} | direct {a[0]:6.1f} us {a[1]:5.0f} TF | F(2x2,3x3) {b[0]:6.1f} us {b[1]:5.0f} TF (algorithmic) x{a[0] / b[0]:.2f} | "
+              f"F(2,3)x {c[0]:6.1f} us {c[1]:5.0f} TF (algorithmic) x{a[0] / c[0]:.2f}")
+    print(f"dense block: direct {tot[0]:.1f} us, F(2x2,3x3) {tot[1]:.1f} us (x{tot[0] / tot[1]:.2f}), F(2,3) along x {tot[2]:.1f} us (x{tot[0] / tot[2]:.2f})")

@@ -327,6 +327,135 @@ static void run_wino(const char* name, const uint4* src, float* sink, unsigned l
     fflush(stdout);
 }
 
+// Fourth part ("winograd1d" case, f16): Winograd F(2,3) along x only.  One unit per wave = 2 output rows x 32 tiles of
+// two pixels (64 pixels wide) x 32 outputs x 16 input channels: 16 patch reads (4 rows x 4 columns), 16 vector adds
+// (v = (d0 - d2, d1 + d2, d2 - d1, d1 - d3) per patch row: 64 v_pk_add_f16), 12 weight-fragment reads (4 positions x 3
+// vertical taps) and 24 MFMAs into 8 accumulators (2 rows x 4 positions: 128 registers, two waves per SIMD); the direct
+// form spends 36 MFMAs on the same work.  Two 4-wave workgroups of 64 KiB per CU.
+constexpr int kLds1d = 64 * 1024;
+__global__ __launch_bounds__(256, 2) void wino1d_kernel(const uint4* __restrict__ src, float* __restrict__ sink, int units,
+                                                        unsigned long long* __restrict__ clk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < kLds1d / 16; i += 256) ((uint4*)smem)[i] = src[(blockIdx.x * (kLds1d / 16) + i) & 0xFFFFF];
+    __syncthreads();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][k][i] = 0.f;
+    auto frag = [&](int f) { return *(const h8*)(smem + (f & 63) * 1024 + lane * 16); };
+    // Patch rows are walked one at a time (as the direct kernel reuses a pixel-row fragment for its vertical taps): row
+    // rho feeds outputs r = rho - ky.  Two row buffers: the multiplies read one while the other is loaded and transformed.
+    h8 A[4], B[4], wf[3][4];
+    auto load_row = [&](h8 (&X)[4], const int f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) X[j] = frag(f + j);
+    };
+    auto xform = [&](h8 (&X)[4], const int op) {
+        if (op == 0) X[0] = sub8(X[0], X[2]);
+        else if (op == 1) X[3] = sub8(X[1], X[3]);
+        else if (op == 2) { const h8 t = X[1] + X[2]; X[2] = sub8(X[2], X[1]); X[1] = t; }
+    };
+    load_row(A, 0);
+#pragma unroll
+    for (int op = 0; op < 3; ++op) xform(A, op);
+    auto row = [&](h8 (&V)[4], h8 (&X)[4], const int rho, const int par) {
+        load_row(X, par * 16 + ((rho + 1) & 3) * 4 + 5);
+        if (rho == 3) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) wf[ky][xi] = frag(32 + par * 12 + ky * 4 + xi);   // next unit's weights
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int m = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int r = rho - ky;
+            if (r < 0 || r > 1) continue;
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                acc[r][xi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ky][xi], V[xi], acc[r][xi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m >= 1 && m <= 3) xform(X, m - 1);
+                ++m;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) wf[ky][xi] = frag(32 + ky * 4 + xi);
+    for (int it = 0; it < units; it += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            row(A, B, 0, par);
+            row(B, A, 1, par);
+            row(A, B, 2, par);
+            row(B, A, 3, par);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += acc[r][k][i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (float)A[k][0] + (float)B[k][1];
+    if (s == 123.456f) sink[blockIdx.x * 256 + tid] = s;
+    if (clk && lane == 0) {
+        const size_t o = ((size_t)blockIdx.x * 4 + (tid >> 6)) * 2;
+        clk[o] = __builtin_amdgcn_s_memtime() - c0;
+        clk[o + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
+static void run_wino1d(const char* name, const uint4* src, float* sink, unsigned long long* clk, double seconds) {
+    const int grid = 1024, units = 6000;
+    auto k = wino1d_kernel;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1d));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    double spent = 0;
+    while (spent < seconds) {
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 5; ++i) k<<<grid, 256, kLds1d>>>(src, sink, units, nullptr);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        spent += ms / 1e3;
+    }
+    CHECK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) k<<<grid, 256, kLds1d>>>(src, sink, units, i == reps - 1 ? clk : nullptr);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double issued = (double)reps * grid * 4 * units * 24.0 * 32768.0;
+    const double algorithmic = issued * 36.0 / 24.0;
+    std::vector<unsigned long long> h((size_t)768 * 4 * 2);
+    CHECK(hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (size_t i = 0; i < h.size(); i += 2)
+        if (h[i + 1]) ghz.push_back((double)h[i] / (double)h[i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    printf("{\"case\": \"%s\", \"tflops_algorithmic\": %.1f, \"frac_of_2500_algorithmic\": %.3f, \"tflops_issued\": %.1f, "
+           "\"ms_per_launch\": %.3f, \"in_kernel_clock_ghz\": %.3f}\n",
+           name, algorithmic / (ms / 1e3) / 1e12, algorithmic / (ms / 1e3) / 2.5e15, issued / (ms / 1e3) / 1e12, ms / reps,
+           ghz.empty() ? 0.0 : ghz[ghz.size() / 2]);
+    fflush(stdout);
+}
+
 template <int SHAPE, bool BF, int STAGING = 0>
 static void run_case(const char* name, const uint4* src, float* sink, unsigned long long* clk, double seconds,
                      const char* pix = nullptr, unsigned long long pix_bytes = 0) {
@@ -381,8 +510,8 @@ int main(int argc, char** argv) {
     float* sink;
     unsigned long long* clk;
     CHECK(hipMalloc((void**)&src, n * 16));
-    CHECK(hipMalloc((void**)&sink, 768 * 256 * 4));
-    CHECK(hipMalloc((void**)&clk, 768 * 4 * 2 * 8));
+    CHECK(hipMalloc((void**)&sink, 1024 * 256 * 4));
+    CHECK(hipMalloc((void**)&clk, 1024 * 4 * 2 * 8));
     CHECK(hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice));
     if (argc > 2 && !strcmp(argv[2], "winograd")) {
         // A/B on one device in one run: the direct loop, the Winograd loop, the Winograd loop without its adds
@@ -390,6 +519,7 @@ int main(int argc, char** argv) {
             run_case<32, false>("direct 3x3, f16 32x32x16, operands from LDS", src, sink, clk, seconds);
             run_wino<1>("winograd F(2x2,3x3), f16: 16 patch + 16 weight reads, 128 v_pk_add_f16, 16 MFMAs per unit", src, sink, clk, seconds);
             run_wino<0>("winograd F(2x2,3x3) without the transform adds (loads and MFMAs only)", src, sink, clk, seconds);
+            run_wino1d("winograd F(2,3) along x: 16 patch + 12 weight reads, 64 v_pk_add_f16, 24 MFMAs per unit, two waves per SIMD", src, sink, clk, seconds);
         }
         return 0;
     }

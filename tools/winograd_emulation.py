@@ -79,6 +79,34 @@ def wino_conv(x, U, bias, round_v, round_final=None):
     return y[:, :, :h, :w] + bias.view(1, -1, 1, 1)
 
 
+def wino1d_weights(w, round_fn_cols):
+    """F(2,3) along x: U[ky][xi] = sum_kx G[xi][kx] g[ky][kx] per (cout, cin), f64 then rounded once."""
+    U = torch.einsum("xk,ocyk->yxoc", G, w.double()).float()    # [3][4][cout][cin]
+    return round_fn_cols(U)
+
+
+def wino1d_conv(x, U, bias, round_v):
+    """x: [N,C,H,W]; U: [3][4][Cout][C].  V = B^T d along x with every add rounded by round_v; M = sum over ky and c in
+    f32; Y = A^T M in f32."""
+    n, c, h, w = x.shape
+    we = (w + 1) // 2 * 2
+    xp = F.pad(x, (1, 1 + we - w, 1, 1))
+    tw = we // 2
+    d = [xp[:, :, :, b:b + 2 * tw:2] for b in range(4)]            # [N,C,H+2,tw] each
+    v = [round_v(d[0] - d[2]), round_v(d[1] + d[2]), round_v(d[2] - d[1]), round_v(d[1] - d[3])]
+    m = []
+    for xi in range(4):
+        acc = None
+        for ky in range(3):
+            t = F.conv2d(v[xi][:, :, ky:ky + h, :], U[ky][xi][:, :, None, None])
+            acc = t if acc is None else acc + t
+        m.append(acc)
+    y = torch.empty((n, U.shape[2], h, we), dtype=torch.float32)
+    y[:, :, :, 0::2] = m[0] + m[1] + m[2]
+    y[:, :, :, 1::2] = m[1] - m[2] - m[3]
+    return y[:, :, :, :w] + bias.view(1, -1, 1, 1)
+
+
 def rrdbnet_emulated(sd, x, num_block, wino, v_round=r16, v_final=None, u_grown_round=r8, nf=64, gc=32):
     """The f16 engine's rounding schedule; dense-block convs direct (wino=False) or F(2x2,3x3) (wino=True)."""
     lre = lambda t: F.leaky_relu(t, 0.2)
@@ -95,6 +123,9 @@ def rrdbnet_emulated(sd, x, num_block, wino, v_round=r16, v_final=None, u_grown_
         if not wino:
             wr = torch.where(grown.view(1, -1, 1, 1), r8(w), r16(w))
             return F.conv2d(inp, wr, b, padding=1)
+        if wino == 2:
+            U = wino1d_weights(w, lambda U: torch.where(grown.view(1, 1, 1, -1), u_grown_round(U), r16(U)))
+            return wino1d_conv(inp, U, b, v_round)
         U = wino_weights(w, lambda U: torch.where(grown.view(1, 1, 1, -1), u_grown_round(U), r16(U)))
         return wino_conv(inp, U, b, v_round, v_final)
 
@@ -136,6 +167,7 @@ def main():
                 ("F(2x2,3x3): V adds in f16, U all f16", dict(wino=True, u_grown_round=r16)),
                 ("F(2x2,3x3): V adds in f32, rounded once to f16 as the MFMA operand, U all f16",
                  dict(wino=True, u_grown_round=r16, v_round=lambda t: t, v_final=r16)),
+                ("F(2,3) along x: V adds in f16, U all f16", dict(wino=2, u_grown_round=r16)),
             )
             for label, kw in variants:
                 out = rrdbnet_emulated(sd, x, nb, **kw)
