@@ -4,7 +4,10 @@ batches), f32 engine against the CPU oracle at the f32 bound, f16 engine at <= 1
 output.  Then, with a third argument, that many standalone convolutions (random channel counts, tile height, cout tile,
 activation, residual, dtype, image size and batch) against torch's fp32 conv2d on operands rounded to the compute
 type, an int8 convolution for every fourth of them against the exact integer convolution, and as many bilinear u8
-resizes at random sizes against the oracle (bit-exact).
+resizes at random sizes against the oracle (bit-exact); the f16 convolutions with input counts in multiples of 32 also in
+their two Winograd forms against the CPU emulation of those (tools/winograd_emulation.py), and every third case a
+channel-attention block in one kernel against its two-launch form (same bits).  Every network also runs a second f16
+engine with an f16 trunk (RCAN: one-kernel blocks; RRDBNet: a Winograd form of the dense-block convolutions).
 Prints one line per failing case and a summary; exit status 1 if anything failed.
 
     python tools/fuzz_shapes.py [cases] [seed] [op_cases]
@@ -59,6 +62,40 @@ def fuzz_ops(rng, cases):
             bad += 1
             print(f"FAIL conv dt={dt} cin={cin} cout={cout} tile={cout_tile} mb={mb} n={n} h={h} w={w} act={act} "
                   f"res={bool(kw)}: {err:.3g} > {OP_TOL[dt]:.2g} * {scale:.3g}", flush=True)
+        if dt == _lib.F16 and cin % 32 == 0:
+            # the two Winograd forms of the same convolution against their CPU emulations (same rounding schedule: what is
+            # left is f32 summation order) and, loosely, against the exact result
+            from tools import winograd_emulation as W
+            for algo in (_lib.ALGO_WINOGRAD, _lib.ALGO_WINOGRAD_X):
+                pw = ops.PackedConv(wt.numpy(), b.numpy(), dt, winograd=algo)
+                gw = ops.conv3x3(ops.Planes.from_nchw(x, dt), pw, out_dtype=_lib.F32).to_nchw().cpu()
+                if algo == _lib.ALGO_WINOGRAD:
+                    emu = W.wino_conv(x, W.wino_weights(wt, W.r16), b, W.r16)
+                else:
+                    emu = W.wino1d_conv(x, W.wino1d_weights(wt, W.r16), b, W.r16)
+                plain = F.conv2d(x, wt, b, padding=1)
+                e1, e2 = float((gw - emu).abs().max()), float((gw - plain).abs().max())
+                sc = max(float(plain.abs().max()), 1e-6)
+                if gw.shape != emu.shape or e1 > 2e-5 * sc or e2 > 5e-3 * sc:
+                    bad += 1
+                    print(f"FAIL winograd algo={algo} cin={cin} cout={cout} n={n} h={h} w={w}: {e1:.3g} / {e2:.3g} on {sc:.3g}", flush=True)
+        if i % 3 == 0:
+            # both convolutions of a channel-attention block in one kernel against the two-launch form: same bits
+            xb, yb = rq("xb", (n, 64, h, w)), rq("yb", (n, 64, h, w))
+            if dt != _lib.F16:
+                xb, yb = xb.half().float(), yb.half().float()
+            g = torch.from_numpy(synth.hash_uniform("g", (n, 64), 4000 + i) * 0.5 + 0.5).cuda()
+            mk = lambda key: ops.PackedConv((synth.hash_uniform(key, (64, 64, 3, 3), 4000 + i) * 0.08).astype(np.float16).astype(np.float32),
+                                            synth.hash_uniform(key + "b", (64,), 4000 + i), _lib.F16, cout_tile=64)
+            p1, p2 = mk("c1"), mk("c2")
+            X, Y = ops.Planes.from_nchw(xb, _lib.F16), ops.Planes.from_nchw(yb, _lib.F16)
+            s1, s2 = ops.Planes(n, 64, h, w, _lib.F16, zero=True), ops.Planes(n, 64, h, w, _lib.F16, zero=True)
+            t = ops.conv3x3(X, p1, act=_lib.ACT_RELU, rows_per_wave=2, in_gate=Y, gate=g, gate_alpha=0.9, in_sum=s1)
+            two = ops.conv3x3(t, p2, rows_per_wave=2).to_nchw().cpu()
+            one = ops.rcab_fused(X, p1, p2, in_gate=Y, gate=g, gate_alpha=0.9, in_sum=s2).to_nchw().cpu()
+            if not torch.equal(one, two) or not torch.equal(s1.to_nchw().cpu(), s2.to_nchw().cpu()):
+                bad += 1
+                print(f"FAIL one-kernel block n={n} h={h} w={w}: max diff {float((one - two).abs().max()):.3g}", flush=True)
         if i % 4 == 0:
             # int8 x int8 -> int32 is exact: the scaled f32 output must equal the integer convolution to 1e-6
             cin8, mb8 = 32 * int(rng.integers(1, 7)), int(rng.choice([2, 3]))
@@ -123,8 +160,13 @@ def main():
         if key not in engines:
             m32, sd = H.build_model(meta, "f32")
             m16, _ = H.build_model(meta, "f16")
-            engines[key] = (m32, m16, {k: torch.from_numpy(v) for k, v in sd.items()})
-        m32, m16, sd = engines[key]
+            # a second f16 engine with an f16 trunk: RCAN then runs its one-kernel blocks, RRDBNet here additionally one
+            # of the Winograd forms of its dense-block convolutions
+            m16b, _ = H.build_model(meta, "f16", trunk_f32=False)
+            if meta["arch"] == "rrdbnet":
+                m16b.engine().set_winograd(1 + key % 2)
+            engines[key] = (m32, m16, {k: torch.from_numpy(v) for k, v in sd.items()}, m16b)
+        m32, m16, sd, m16b = engines[key]
         x = H.input_for(meta)
         want = H.oracle_forward(meta, sd, x)
         got = m32(x.cuda()).cpu()
@@ -139,6 +181,11 @@ def main():
         mse = float((d ** 2).mean())
         psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
         ok16 = got_u8.shape == want_u8.shape and float(d.max()) <= 1 and psnr >= 50.0
+        got_b = m16b.engine().forward_u8(torch.from_numpy(img).cuda(), _lib.ROUND_HALF_UP).cpu().float()
+        db = (got_b - want_u8).abs()
+        mse_b = float((db ** 2).mean())
+        ok16 = ok16 and float(db.max()) <= 1 and (mse_b == 0 or 10 * np.log10(255.0 ** 2 / mse_b) >= 50.0)
+        d = torch.maximum(d, db)
         worst32 = max(worst32, err / H.f32_tol(meta))
         worst_lsb, worst_db = max(worst_lsb, float(d.max())), min(worst_db, psnr)
         if not (ok32 and ok16):
