@@ -26,6 +26,7 @@
 //   ds_read_b128 without a swizzle) and every tap is a constant offset from a lane's base address.
 // The order of the multiply-accumulates per output equals the direct kernel's (stage, horizontal tap, vertical tap), so
 // conv1 and conv2 produce the bits the unfused pair produces; only the pooled sums see different tile shapes.
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -85,6 +86,30 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int x0 = tx * G::TW, y0 = ty * G::TH;
     const int nstage = p.ncb;   // 16-channel planes of x' (= planes of the intermediate)
+#ifdef SRMI_STAMPS
+    // diagnostic build: lane 0 of every wave records s_memtime at each phase boundary into [workgroup][wave][40];
+    // slot 39 holds (XCC_ID << 32) | HW_ID
+    unsigned long long* stamp_buf = (unsigned long long*)p.tail_out;
+    int stamp_i = 0;
+    const size_t stamp_base = (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * kNW + wave) * 40;
+    if (stamp_buf && lane == 0) {
+        unsigned hw_, xcc_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        stamp_buf[stamp_base + 39] = ((unsigned long long)xcc_ << 32) | hw_;
+    }
+#define STAMP()                                                                                   \
+    do {                                                                                          \
+        if (stamp_buf && lane == 0 && stamp_i < 39) {                                             \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            stamp_buf[stamp_base + stamp_i++] = t_;                                               \
+        }                                                                                         \
+    } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
 
     // ---- gated loader: per-lane source offsets of this wave's x' pieces ---------------------------------
     // LDS chunk i of a stage = channel half i / 448, patch pixel i % 448 (row-major 12 x 36); piece k = chunks 64k..64k+63.
@@ -205,12 +230,14 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
 #pragma unroll
         for (int q = 0; q < G::APW; ++q) gate_fetch(q, true, ra, rt);
     }
+    STAMP();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::BPW + 2 * G::APW) : "memory");
     if (tid < nstage * 16) ((float*)(smem + G::GATE_OFF))[tid] = gate_v;
     if (tid < 64) ((float*)(smem + G::BIAS1_OFF))[tid] = bias1_v;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the gate vector is in LDS
     __builtin_amdgcn_sched_barrier(0);
+    STAMP();
     {
         const int s1 = nstage > 1 ? 1 : 0;
         const auto rx = sum_rsrc(0);
@@ -219,6 +246,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
 #pragma unroll
         for (int st = 0; st < kGateSteps; ++st) gate_step(st, 0, xslot0, rx, true, nstage > 1, ra, rt);
     }
+    STAMP();
 
     // ---- conv1 main loop ------------------------------------------------------------------------------------
     struct FragA {
@@ -233,6 +261,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kGateYounger) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        STAMP();
         const int cur = s & 1;
         const bool more = s + 1 < nstage, more2 = s + 2 < nstage;
         const int sn = more ? s + 1 : s, sn2 = more2 ? s + 2 : s;
@@ -290,6 +319,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP();
     };
     for (int s = 0; s + 1 < nstage; ++s) conv1_stage(s, std::false_type());
     conv1_stage(nstage - 1, std::true_type());
@@ -299,6 +329,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    STAMP();
     char* const w2slot0 = smem + G::R2;
     {
         const auto r0 = w2_rsrc(0);
@@ -342,6 +373,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
                 }
     }
 
+    STAMP();
     // ---- conv2 ---------------------------------------------------------------------------------------------------
     f32x16 acc2[2][2];
 #pragma unroll
@@ -362,6 +394,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        STAMP();
         const int cur = s & 1;
         if (s >= 1 && s + 1 < nstage) {
             const auto rb = w2_rsrc(s + 1);
@@ -407,16 +440,23 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
         __builtin_amdgcn_sched_barrier(0);
         mul(f0);
         __builtin_amdgcn_sched_barrier(0);
+        STAMP();
     }
     // the epilogue's bias and tile-sum scratch alias region 2
     __syncthreads();
     if (tid < 64) ((float*)(smem + G::R2 + G::BIAS_OFFSET))[tid] = p.bias2[tid];
     __syncthreads();
+    STAMP();
     const EpiCtx ctx{n, 0, tile, x0, y0, wave, lx, lh, tid};
     const float* lds_bias = (const float*)(smem + G::R2 + G::BIAS_OFFSET);
     float* lds_red = (float*)(smem + G::R2);
     if (p.out.dtype == DT) epilogue<DT, 2, 2, DT, -1, false, -1>(p, ctx, acc2, lds_bias, lds_red);
     else epilogue<DT, 2, 2, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc2, lds_bias, lds_red);
+#ifdef SRMI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores and atomics of the epilogue count as its time
+    STAMP();
+#endif
+#undef STAMP
 #endif
 }
 
@@ -477,6 +517,9 @@ extern "C" int srmi_rcab_fused(const srmi_rcab_desc_t* d, void* hip_stream) {
     p.ca_w1 = d->ca.w1; p.ca_b1 = d->ca.b1; p.ca_w2 = d->ca.w2; p.ca_b2 = d->ca.b2;
     p.ca_scale = d->ca.scale; p.ca_cr = d->ca.cr;
     p.ca_inv_hw = 1.f / ((float)d->h * (float)d->w);
+#if defined(SRMI_DIAG) && defined(SRMI_STAMPS)
+    p.tail_out = getenv("SRMI_STAMP_PTR") ? (void*)strtoull(getenv("SRMI_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
     if (rcab_configure()) return -1;
     dim3 grid(p.tiles_x * p.tiles_y, 1, p.n);
     hipLaunchKernelGGL(rcab_fused_kernel, grid, dim3(64 * kNW), RcabGeom::LDS_BYTES, (hipStream_t)hip_stream, p);
