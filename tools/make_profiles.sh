@@ -14,6 +14,14 @@ timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 $
 timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 $R/bench.py --steps 1 --warmup 1 --batch 2 --lanes 1 --no-cpu-baseline --no-side-configs > $O/pmc_write.log 2>&1
 python3 $R/tools/pmc_summary.py $O/pmc_fetch srmi > $O/pmc_summary.txt
 python3 $R/tools/pmc_summary.py $O/pmc_write srmi >> $O/pmc_summary.txt
+# the same two passes for the RCAN and EDSR side configurations (one bench step each, one lane)
+for net in rcan edsr; do
+  timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$net -o p -- python3 $R/bench.py --model $net --steps 1 --warmup 1 --batch 2 --lanes 1 --no-cpu-baseline --no-side-configs > $O/pmc_fetch_$net.log 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$net -o p -- python3 $R/bench.py --model $net --steps 1 --warmup 1 --batch 2 --lanes 1 --no-cpu-baseline --no-side-configs > $O/pmc_write_$net.log 2>&1
+  python3 $R/tools/pmc_summary.py $O/pmc_fetch_$net srmi > $O/pmc_summary_$net.txt
+  python3 $R/tools/pmc_summary.py $O/pmc_write_$net srmi >> $O/pmc_summary_$net.txt
+  rm -rf $O/pmc_fetch_$net $O/pmc_write_$net
+done
 cp $O/trace_default/*kernel_stats.csv $O/kernel_stats_default.csv
 cp $O/trace_lanes1/*kernel_stats.csv $O/kernel_stats_lanes1.csv
 grep -h '^{' $O/trace_default.log > $O/bench_under_rocprof_default.json || true
