@@ -56,7 +56,6 @@ struct RcabGeom {
     static constexpr int SPARE_OFF = GATE_OFF + 256;                         // 1 KiB absorbing writes of pieces a wave does not own
     static constexpr int BIAS1_OFF = SPARE_OFF + 1024;                       // float[64]: bias of the first convolution
     static constexpr int LDS_BYTES = BIAS1_OFF + 256;                        // 81920 = half a CU's LDS
-    static constexpr int BIAS_OFFSET = 8192;                                 // within region 2, behind the tile sums
 };
 static_assert(2 * RcabGeom::W_BYTES <= RcabGeom::R1_BYTES && 2 * RcabGeom::X_BYTES <= RcabGeom::R2_BYTES, "rings fit their regions");
 static_assert(2 * RcabGeom::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
@@ -113,8 +112,11 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
 
     // ---- gated loader: per-lane source offsets of this wave's x' pieces ---------------------------------
     // LDS chunk i of a stage = channel half i / 448, patch pixel i % 448 (row-major 12 x 36); piece k = chunks 64k..64k+63.
+    // (conditions combined with & on values read once: short-circuit forms compile to a branch per term, each with its
+    // own reload of the image size from the argument block)
     unsigned aoff[G::APW];
     unsigned keep = 0;   // bit j: piece j of this lane is an in-image pixel of the tile's interior (stored to in_sum)
+    const unsigned img_h = (unsigned)p.h, img_w = (unsigned)p.w;
 #pragma unroll
     for (int j = 0; j < G::APW; ++j) {
         const int k = wave + kNW * j;
@@ -122,10 +124,10 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
         const int pp = (k - c * G::XC_PIECES) * 64 + lane;
         const int row = pp / G::XW, col = pp - row * G::XW;
         const int gy = y0 - 2 + row, gx = x0 - 2 + col;
-        const bool ok = k < G::X_PIECES && pp < G::NPX && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-        aoff[j] = ok ? ((unsigned)(gy * p.w + gx) * 32u + (unsigned)c * 16u) : SRMI_OOB_OFFSET;
-        const bool interior = row >= 2 && row < 2 + G::TH && col >= 2 && col < 2 + G::TW;
-        if (ok && interior) keep |= 1u << j;
+        const bool ok = (k < G::X_PIECES) & (pp < G::NPX) & ((unsigned)gy < img_h) & ((unsigned)gx < img_w);
+        aoff[j] = ok ? ((unsigned)gy * img_w + (unsigned)gx) * 32u + (unsigned)c * 16u : SRMI_OOB_OFFSET;
+        const bool interior = ((unsigned)(row - 2) < (unsigned)G::TH) & ((unsigned)(col - 2) < (unsigned)G::TW);
+        keep |= (ok & interior) ? 1u << j : 0u;
     }
     const char* in_img = p.in.ptr + (long long)n * p.in.img_stride_b;
     const char* gate_img = p.in_gate.ptr + (long long)n * p.in_gate.img_stride_b;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
         xb[b] = lh * G::XC_BYTES + (r1 * G::XW + c1) * 16;
         tpix[b] = pp1 < G::NPT ? pp1 : -1;
         const int gy = y0 - 1 + r1, gx_ = x0 - 1 + c1;
-        tin[b] = gy >= 0 && gy < p.h && gx_ >= 0 && gx_ < p.w;
+        tin[b] = ((unsigned)gy < img_h) & ((unsigned)gx_ < img_w);
     }
     const int bm = (lx >> 3) & 1;   // weight-row swizzle term of the packed weight image
 
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
     // the gate vector is requested first and waited for alone: the weight pieces and the x' pieces behind it stay in flight
     const float gate_v = p.gate[(long long)n * nstage * 16 + (tid < nstage * 16 ? tid : 0)];
     const float bias1_v = p.bias[tid & 63];
+    const float bias2_v = p.bias2[tid & 63];
     {
         const auto ra = pixel_rsrc(0);
         const auto rt = gate_rsrc(0);
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     STAMP();
+    if (tid < 64) ((float*)(smem + G::GATE_OFF))[tid] = bias2_v;   // conv1 was the gate vector's last reader
     char* const w2slot0 = smem + G::R2;
     {
         const auto r0 = w2_rsrc(0);
@@ -351,28 +355,40 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { b1r[h][q][j] = v0[j]; b1r[h][q][4 + j] = v1[j]; }
             }
+        // relu and the saturating conversion in one median: med3(v, 0, 65504) = clamp(max(v, 0)) also for infinities and
+        // NaN (the minimum of the other two); pairs of neighbouring channels convert together
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int b = 0; b < G::BLK_PER_WAVE; ++b)
+        for (int b = 0; b < G::BLK_PER_WAVE; ++b) {
+            u32x4 pk[2][2];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    f16x8 t8;
+                    float v[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // half-wave exchange: afterwards the lane owns channels 16 q + 8 lh .. + 7 of the 32-channel half
                         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc1[b][h][8 * q + j]),
                                                                          __float_as_uint(acc1[b][h][8 * q + 4 + j]), false, false);
-                        const float v0 = fmaxf(__uint_as_float(sw[0]) + b1r[h][q][j], 0.f);
-                        const float v1 = fmaxf(__uint_as_float(sw[1]) + b1r[h][q][4 + j], 0.f);
-                        t8[j] = tin[b] ? to_f16_sat(v0) : (_Float16)0.f;
-                        t8[4 + j] = tin[b] ? to_f16_sat(v1) : (_Float16)0.f;
+                        v[j] = __builtin_amdgcn_fmed3f(__uint_as_float(sw[0]) + b1r[h][q][j], 0.f, 65504.f);
+                        v[4 + j] = __builtin_amdgcn_fmed3f(__uint_as_float(sw[1]) + b1r[h][q][4 + j], 0.f, 65504.f);
                     }
-                    if (tpix[b] >= 0)
-                        *(f16x8*)(smem + G::R1 + (h * 2 + q) * G::TP_BYTES + lh * G::TC_BYTES + tpix[b] * 16) = t8;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f16x2 hh = {(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
+                        pk[h][q][i] = tin[b] ? __builtin_bit_cast(unsigned, hh) : 0u;
+                    }
                 }
+            if (tpix[b] >= 0) {
+                char* const dst = smem + G::R1 + lh * G::TC_BYTES + tpix[b] * 16;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) *(u32x4*)(dst + (h * 2 + q) * G::TP_BYTES) = pk[h][q];
+            }
+        }
     }
-
     STAMP();
     // ---- conv2 ---------------------------------------------------------------------------------------------------
     f32x16 acc2[2][2];
@@ -442,13 +458,12 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
         __builtin_amdgcn_sched_barrier(0);
         STAMP();
     }
-    // the epilogue's bias and tile-sum scratch alias region 2
-    __syncthreads();
-    if (tid < 64) ((float*)(smem + G::R2 + G::BIAS_OFFSET))[tid] = p.bias2[tid];
+    // the epilogue's tile-sum scratch aliases region 2: everybody must be out of conv2 (its bias sits in the gate
+    // vector's place since conv1 ended)
     __syncthreads();
     STAMP();
     const EpiCtx ctx{n, 0, tile, x0, y0, wave, lx, lh, tid};
-    const float* lds_bias = (const float*)(smem + G::R2 + G::BIAS_OFFSET);
+    const float* lds_bias = (const float*)(smem + G::GATE_OFF);
     float* lds_red = (float*)(smem + G::R2);
     if (p.out.dtype == DT) epilogue<DT, 2, 2, DT, -1, false, -1>(p, ctx, acc2, lds_bias, lds_red);
     else epilogue<DT, 2, 2, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc2, lds_bias, lds_red);
