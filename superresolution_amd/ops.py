@@ -205,7 +205,7 @@ def conv3x3(x: Planes, pc: PackedConv, *, act=0, up2=False, alpha=1.0, res1: Pla
 
 
 def rcab_fused(x: Planes, pc1: PackedConv, pc2: PackedConv, *, in_gate: Planes = None, gate: torch.Tensor = None,
-               gate_alpha=1.0, in_sum: Planes = None, attention=None):
+               gate_alpha=1.0, in_sum: Planes = None, attention=None, out: Planes = None):
     """conv2(relu(conv1(x'))) in one launch, x' = x + gate_alpha * (in_gate * gate[n][c]) (srmi_rcab_fused).  Without
     in_gate the block's input is x itself.  attention: (w1, b1, w2, b2) of the CALayer -> also returns scale[n][c]."""
     n, c, h, w = x.n, x.c, x.h, x.w
@@ -221,7 +221,8 @@ def rcab_fused(x: Planes, pc1: PackedConv, pc2: PackedConv, *, in_gate: Planes =
         keep.append(zeros)
         d.in_gate, d.gate, d.gate_alpha = x.view(), zeros.data_ptr(), 0.0
     d.w1, d.b1, d.w2, d.b2 = pc1.w.data_ptr(), pc1.b.data_ptr(), pc2.w.data_ptr(), pc2.b.data_ptr()
-    out = Planes(n, c, h, w, x.dtype)
+    if out is None:
+        out = Planes(n, c, h, w, x.dtype)
     d.out = out.view()
     att_scale = None
     if attention is not None:
@@ -235,8 +236,8 @@ def rcab_fused(x: Planes, pc1: PackedConv, pc2: PackedConv, *, in_gate: Planes =
         d.ca_cr = b1.numel()
         keep += [w1, b1, w2, b2, att_sums, att_count]
     check(lib().srmi_rcab_fused(C.byref(d), _stream()), "rcab_fused")
-    torch.cuda.current_stream().synchronize()
     if attention is not None:
+        torch.cuda.current_stream().synchronize()
         if int(att_sums.abs().max()) or int(att_count.abs().max()):
             raise _lib.SrmiError("rcab_fused: attention accumulators were not left at zero")
         del keep
