@@ -82,7 +82,10 @@ static int load_model_body(FILE* f, long file_size, const char* path, int want_a
     d.n_groups = hdr[4]; d.grow_ch = hdr[5]; d.reduction = hdr[6]; d.with_meanshift = hdr[7];
     d.res_scale = res_scale;
     d.dtype = env_dtype();
-    d.trunk_f32 = 1;
+    // SRMI_TRUNK_F32=0: the residual trunk in the compute type instead of an f32 copy beside it (faster; RCAN then runs its
+    // blocks as one kernel each)
+    const char* tf = getenv("SRMI_TRUNK_F32");
+    d.trunk_f32 = !(tf && !strcmp(tf, "0"));
     d.device = device;
     if (want_arch && d.arch != want_arch) SRMI_FAIL("%s holds architecture %d, expected %d", path, d.arch, want_arch);
     srmi_model_t* m = nullptr;
@@ -143,10 +146,11 @@ static int load_model_body(FILE* f, long file_size, const char* path, int want_a
     {
         const char* g8 = getenv("SRMI_GROWTH_ROUND8");
         const bool round8 = d.arch == SRMI_ARCH_RRDBNET && d.dtype == SRMI_F16 && !(g8 && !strcmp(g8, "0"));
-        fprintf(stderr, "[INFO] %s: precision %s%s%s, f32 residual trunk, device %d\n", path,
+        fprintf(stderr, "[INFO] %s: precision %s%s%s, %s residual trunk, device %d\n", path,
                 d.dtype == SRMI_F32 ? "f32" : d.dtype == SRMI_BF16 ? "bf16" : "f16",
                 srmi_model_get_w8a8(m) ? " + w8a8 dense blocks (int8, calibrated ranges from the weight file)" : "",
-                (round8 && !srmi_model_get_w8a8(m)) ? " (dense-block grown channels at 8 significant bits)" : "", device);
+                (round8 && !srmi_model_get_w8a8(m)) ? " (dense-block grown channels at 8 significant bits)" : "",
+                (d.trunk_f32 || d.dtype == SRMI_F32) ? "f32" : d.dtype == SRMI_BF16 ? "bf16" : "f16", device);
     }
     *out = m;
     *desc_out = d;

@@ -82,6 +82,33 @@ def test_realesrgan_runner(tmp_path):
     assert L.realesrgan_init(None, C.byref(ctx)) == -1
 
 
+def test_runner_trunk_switch(tmp_path, monkeypatch):
+    """SRMI_TRUNK_F32=0 puts a runner context on the half-precision trunk (RCAN: one-kernel blocks): same bytes as the
+    Python engine built with trunk_f32=False, and as before within the half-precision bound of the oracle."""
+    L = _lib.lib()
+    meta = dict(arch="rcan", scale=4, n_resgroups=2, n_resblocks=3, seed=44, input="range")
+    model, sd = H.build_model(meta, "f16", trunk_f32=False)
+    assert model.engine().fused_rcab()
+    path = str(tmp_path / "RCAN_BIX4_test.srmi")
+    export.save_weights(model, path)
+    img = synth.smooth_image(339, 510, 6)
+    want = model.forward_u8(img, _lib.ROUND_HALF_UP).numpy()
+    outs = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("SRMI_TRUNK_F32", env)
+        ctx = MeanshiftCtx()
+        assert L.rcan_init(path.encode(), C.byref(ctx)) == 0, L.srmi_last_error().decode()
+        out = C.c_void_p()
+        assert L.rcan_inference(C.byref(ctx), img.ctypes.data_as(C.c_void_p), C.byref(out)) == 0
+        outs[env] = _take(out, 1356, 2040)
+        assert L.rcan_release(C.byref(ctx)) == 0
+    assert np.array_equal(outs["0"], want)
+    with torch.no_grad():
+        ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(img)), O.ROUND_HALF_UP)[0]
+    for env, got in outs.items():
+        assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and O.psnr_u8(got, ref) >= 50, env
+
+
 @pytest.mark.parametrize("name", ["edsr", "rcan"])
 @pytest.mark.parametrize("core", [False, True])
 def test_meanshift_runners(tmp_path, name, core):
