@@ -299,6 +299,26 @@ def test_permutes(dt, name, tol, golden_dir):
     assert np.array_equal(O.nearest_up2(x).numpy(), g["near_out"])
 
 
+@pytest.mark.parametrize("dt,name", [(_lib.F16, "f16"), (_lib.BF16, "bf16")])
+def test_aux_kernels_wide_paths(dt, name):
+    """The 16-byte / 64-byte-per-thread forms of the standalone operators: PixelShuffle(2) on half tensors whose shuffled
+    channel count is a multiple of 16, nearest x2 and the channel sums with several loads in flight per thread (long
+    pixel segments), at ragged sizes and batch 2, against torch bit for bit (the sums: to f32 summation error)."""
+    for (n, c_in, h, w) in [(2, 64, 7, 13), (1, 128, 33, 31), (2, 256, 17, 65), (1, 64, 1, 1)]:
+        x = q(rnd(f"psw{c_in}", (n, c_in, h, w), 7), dt)
+        got = ops.pixel_shuffle(ops.Planes.from_nchw(x, dt), 2).to_nchw().cpu()
+        assert torch.equal(got, F.pixel_shuffle(x, 2)), f"pixel_shuffle wide {name} {(n, c_in, h, w)}"
+    for (n, c, h, w) in [(2, 64, 9, 14), (1, 32, 31, 67), (1, 16, 1, 3)]:
+        x = q(rnd(f"nrw{c}", (n, c, h, w), 8), dt)
+        got = ops.nearest_up2(ops.Planes.from_nchw(x, dt)).to_nchw().cpu()
+        assert torch.equal(got, O.nearest_up2(x)), f"nearest_up2 {name} {(n, c, h, w)}"
+    for (n, c, h, w) in [(1, 64, 130, 257), (2, 32, 61, 90), (1, 16, 3, 5)]:
+        x = q(rnd(f"csw{c}", (n, c, h, w), 9), dt)
+        sums = ops.channel_sums(ops.Planes.from_nchw(x, dt)).cpu()
+        ref = x.double().sum(dim=(2, 3))
+        assert float((sums.double() - ref).abs().max()) <= 1e-5 * float(x.abs().double().sum(dim=(2, 3)).max()), f"channel_sums {name}"
+
+
 def test_resize_bilinear_u8():
     for (ih, iw, oh, ow) in [(37, 53, 339, 510), (400, 600, 256, 256), (256, 256, 256, 256), (5, 7, 3, 2)]:
         img = synth.random_image(ih, iw, 7)
