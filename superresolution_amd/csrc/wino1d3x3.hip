@@ -85,11 +85,38 @@ __global__ __launch_bounds__(64 * kNW, 2) void wino1d3x3_kernel(const ConvParams
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int x0 = tx * G::TW, y0 = ty * G::TH;
     const int nstage = p.ncb;
+#ifdef SRMI_STAMPS
+    // diagnostic build: lane 0 of every wave records s_memtime at each phase boundary into [workgroup][wave][40];
+    // slot 39 holds (XCC_ID << 32) | HW_ID
+    unsigned long long* stamp_buf = (unsigned long long*)p.tail_out;
+    int stamp_i = 0;
+    const size_t stamp_base = (((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kNW + wave) * 40;
+    if (stamp_buf && lane == 0) {
+        unsigned hw_, xcc_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        stamp_buf[stamp_base + 39] = ((unsigned long long)xcc_ << 32) | hw_;
+    }
+#define STAMP()                                                                                   \
+    do {                                                                                          \
+        if (stamp_buf && lane == 0 && stamp_i < 39) {                                             \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            stamp_buf[stamp_base + stamp_i++] = t_;                                               \
+        }                                                                                         \
+    } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
 
     // ---- LDS-DMA source offsets of this wave's patch pieces (the same for every stage) ----------
     // LDS chunk q of the patch = channel half q / 704, slot pp = q % 704 = row * 66 + s; s < 33: patch column 2s, else
     // patch column 2 (s - 33) + 1.
+    // (conditions combined with & on values read once: short-circuit forms compile to a branch per term, each with its
+    // own reload of the image size from the argument block)
     unsigned aoff[G::APW];
+    const unsigned img_h = (unsigned)p.h, img_w = (unsigned)p.w;
 #pragma unroll
     for (int j = 0; j < G::APW; ++j) {
         const int k = wave + kNW * j;
@@ -98,8 +125,8 @@ __global__ __launch_bounds__(64 * kNW, 2) void wino1d3x3_kernel(const ConvParams
         const int row = pp / G::PW, s = pp - row * G::PW;
         const int xi = s < G::HALF ? 2 * s : 2 * (s - G::HALF) + 1;
         const int gy = y0 - 1 + row, gx = x0 - 1 + xi;
-        const bool ok = k < G::A_PIECES && pp < G::NPIX && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-        aoff[j] = ok ? ((unsigned)(gy * p.w + gx) * 32u + (unsigned)c * 16u) : SRMI_OOB_OFFSET;
+        const bool ok = (k < G::A_PIECES) & (pp < G::NPIX) & ((unsigned)gy < img_h) & ((unsigned)gx < img_w);
+        aoff[j] = ok ? ((unsigned)gy * img_w + (unsigned)gx) * 32u + (unsigned)c * 16u : SRMI_OOB_OFFSET;
     }
     const char* in_img = p.in.ptr + (long long)n * p.in.img_stride_b;
     const char* w_tile = p.wpk + (size_t)ct * nstage * G::B_BYTES;
@@ -157,29 +184,36 @@ __global__ __launch_bounds__(64 * kNW, 2) void wino1d3x3_kernel(const ConvParams
     const float bias_v = tid < 32 ? p.bias[ct * 32 + tid] : 0.f;
 #pragma unroll
     for (int q = 0; q < G::PPW; ++q) issue_piece(0, q);
+    STAMP();
 
     // ---- main loop: one stage = four patch rows; row rho feeds output rows r = rho - ky -------------------------
+    // Rows 0 and 1 are requested at the stage's start; row rho + 2 is requested into the registers of row rho as soon as
+    // its last multiply has issued, and transformed behind the last four multiplies of row rho + 1: every LDS read has
+    // at least four multiplies to arrive before its first use, only row 0's read and transform are exposed per stage.
+    // (A stage takes a lone wave 1.5 k cycles for 0.77 k of multiplies either way: a wave issues its vector adds, LDS
+    // reads and multiplies one after the other, and it is the second wave of the SIMD that fills the matrix pipe.)
     // (Measured and not kept: the stage barrier behind the stage's last LDS read, with the next stage's first row loaded
     // and transformed under the last row's multiplies.  It asks for the next stage four multiplies earlier, and the wait
-    // for its LDS-DMA costs more than the bubble it removes: 112.1 against 109.1 us per dense block.)
+    // for its LDS-DMA costs more than the bubble it removes.)
     h8 Ra[4], Rb[4], wf[3][4];
     for (int s = 0; s < nstage; ++s) {
         // stage s has landed for everybody, and everybody is done reading the other slot
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        STAMP();
         const char* slot = smem + (s & 1) * G::STAGE_BYTES;
         ld_row(Ra, slot, 0);
         ld_w(wf[0], slot, 0);
+        ld_row(Rb, slot, 1);
+        ld_w(wf[1], slot, 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int op = 0; op < 4; ++op) xf_step(Ra, op);
         __builtin_amdgcn_sched_barrier(0);
         int mi = 0;   // multiply index within the stage: the next stage's pieces go behind the first PPW of them
         auto row = [&](h8 (&V)[4], h8 (&X)[4], const int rho) {
-            // the next patch row and the next vertical tap's weights, requested before this row's multiplies
-            if (rho < 3) ld_row(X, slot, rho + 1);
-            if (rho < 2) ld_w(wf[rho + 1], slot, rho + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            const int nm = (rho == 0 || rho == 3) ? 4 : 8;   // multiplies of this row
             int m = 0;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -190,22 +224,22 @@ __global__ __launch_bounds__(64 * kNW, 2) void wino1d3x3_kernel(const ConvParams
                     acc[r][xi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ky][xi], V[xi], acc[r][xi], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (mi < G::PPW) issue_piece(s + 1, mi);
-                    // the next row's transform behind this row's second to fourth multiply (its loads have had one
-                    // multiply to arrive; the rest of their latency is the other wave's turn on the SIMD)
-                    if (rho < 3 && m >= 1 && m <= 3) {
-                        xf_step(X, m - 1);
-                        if (m == 3) xf_step(X, 3);
-                    }
+                    if (rho < 3 && m >= nm - 4) xf_step(X, m - (nm - 4));
                     ++m;
                     ++mi;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            // this row's registers are free once its last multiply has issued
+            if (rho < 2) ld_row(V, slot, rho + 2);
+            if (rho == 0) ld_w(wf[2], slot, 2);
+            __builtin_amdgcn_sched_barrier(0);
         };
         row(Ra, Rb, 0);
         row(Rb, Ra, 1);
         row(Ra, Rb, 2);
         row(Rb, Ra, 3);
+        STAMP();
     }
 
     // ---- output transform: (m0 + m1 + m2, m1 - m2 - m3) per output row ----------------------------------------------
@@ -221,6 +255,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void wino1d3x3_kernel(const ConvParams
     __syncthreads();
     if (tid < 32) ((float*)(smem + G::BIAS_OFFSET))[tid] = bias_v;
     __syncthreads();
+    STAMP();
 
     const EpiCtx ctx{n, ct, tile, x0, y0, wave, lx, lh, tid};
     const float* lds_bias = (const float*)(smem + G::BIAS_OFFSET);
@@ -242,6 +277,11 @@ __global__ __launch_bounds__(64 * kNW, 2) void wino1d3x3_kernel(const ConvParams
     } else {
         epilogue<DT, 4, 1, kAnyType, kAnyType, true, kAnyType, 2>(p, ctx, o, lds_bias, lds_red);
     }
+#ifdef SRMI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores count as its time
+    STAMP();
+#endif
+#undef STAMP
 #endif
 }
 
