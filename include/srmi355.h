@@ -229,7 +229,9 @@ int srmi_conv_first(const srmi_conv_first_desc_t* d, void* hip_stream);
  * ca.scale).  The block's last line, out * scale * res_scale + x', is again left to the consumer's gated input.
  * For a block whose input is a plain tensor pass in_gate = in and gate_alpha = 0 (gate must still point at finite
  * floats).  f16 tensors, c = 64; w1 / w2 from srmi_pack_conv3x3(SRMI_F16, 64, 64, 64, 1, ...).  `out` and in_sum must not
- * alias `in` or in_gate (other workgroups still read their halos).
+ * alias `in` or in_gate (other workgroups still read their halos).  With a gated input, `in` and in_sum may be f32
+ * tensors (the residual trunk kept in single precision, planes below 2 GiB): x' is then formed and stored in f32 and
+ * the convolution sees its f16 cast, as srmi_ca_apply's two outputs would be.
  */
 typedef struct {
     int32_t dtype;        /* SRMI_F16 */

@@ -836,9 +836,9 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
     // consumes it forms it while loading.
     const bool fused = m->fuse_attention && (T == SRMI_F16 || T == SRMI_BF16) && nf <= 256 &&
                        (!split || gate_rows_per_wave(m, h) == 2);
-    // ... and with an f16 trunk and 64 features both convolutions of a block run in one kernel, which reads the
-    // previous block's body while it writes its own: two body buffers
-    const bool rcab = fused && m->fuse_rcab && T == SRMI_F16 && !split && nf == 64 && !m->mb_override;
+    // ... and with f16 operands and 64 features both convolutions of a block run in one kernel (the trunk in f16, or in
+    // f32 beside the f16 operands), which reads the previous block's body while it writes its own: two body buffers
+    const bool rcab = fused && m->fuse_rcab && T == SRMI_F16 && (!split || TR == SRMI_F32) && nf == 64 && !m->mb_override;
     Buf Yb[2] = {A.take(nf, h, w, T), rcab ? A.take(nf, h, w, T) : Buf()};
     int yk = 0;   // Yb[yk] holds the latest block body
     Buf H = A.take(nf, h, w, TR);
@@ -874,10 +874,15 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
                     char name2[96];
                     snprintf(name2, sizeof(name2), "body.%d.body.%d.body.2", g, b);
                     const Exec::Attention att{&m->cas[ca_index++], cr, ca_sums, ca_count, scale};
-                    const srmi_tensor_t in = trunk_view();
-                    const Exec::Gate gate{tv(Yb[yk]), scale, d.res_scale, tv(XT[k ^ 1])};
+                    // a group's first block reads the trunk's compute-dtype copy; the others form their input from the
+                    // trunk (in its own precision) and the previous block's body, and store it on the way
+                    const srmi_tensor_t in = pending ? trunk_view() : tv(XT[k]);
+                    const Exec::Gate gate{tv(Yb[yk]), scale, d.res_scale, split ? tv(XR[kr ^ 1]) : tv(XT[k ^ 1])};
                     if (ex->rcab(name, name2, in, h, w, pending ? &gate : nullptr, scale, tv(Yb[yk ^ 1]), att)) return -1;
-                    if (pending) k ^= 1;
+                    if (pending) {
+                        if (split) { kr ^= 1; trunk_in_xr = true; }
+                        else k ^= 1;
+                    }
                     yk ^= 1;
                     pending = true;
                     continue;

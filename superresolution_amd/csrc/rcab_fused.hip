@@ -61,6 +61,10 @@ static_assert(2 * RcabGeom::W_BYTES <= RcabGeom::R1_BYTES && 2 * RcabGeom::X_BYT
 static_assert(2 * RcabGeom::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 static_assert(kNW == 4, "four waves per workgroup");
 
+// XF32: `in` and `in_sum` are f32 tensors (the residual trunk kept in single precision): a 16-byte chunk of a stage is
+// then the whole 32-byte pixel of one f32 plane (plane 2 s + chunk), fetched and stored as two 16-byte halves; the
+// multiplies see its half-precision cast, in_sum the f32 value.
+template <bool XF32>
 __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = RcabGeom;
@@ -133,9 +137,30 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
     const char* gate_img = p.in_gate.ptr + (long long)n * p.in_gate.img_stride_b;
     char* sum_img = p.in_sum.ptr ? p.in_sum.ptr + (long long)n * p.in_sum.img_stride_b : nullptr;
     const unsigned plane_bytes = p.in_plane_bytes;
-    auto pixel_rsrc = [&](int s) { return make_rsrc(in_img + (long long)s * p.in.plane_stride_b, plane_bytes); };
+    auto pixel_rsrc = [&](int s) {
+        if constexpr (XF32)  // a window over the two f32 planes that hold the stage's 16 channels
+            return make_rsrc(in_img + (long long)(2 * s) * p.in.plane_stride_b, (unsigned)p.in.plane_stride_b + plane_bytes);
+        else
+            return make_rsrc(in_img + (long long)s * p.in.plane_stride_b, plane_bytes);
+    };
     auto gate_rsrc = [&](int s) { return make_rsrc(gate_img + (long long)s * p.in_gate.plane_stride_b, plane_bytes); };
-    auto sum_rsrc = [&](int s) { return make_rsrc(sum_img + (long long)s * p.in_sum.plane_stride_b, sum_img ? plane_bytes : 0u); };
+    auto sum_rsrc = [&](int s) {
+        if constexpr (XF32)
+            return make_rsrc(sum_img + (long long)(2 * s) * p.in_sum.plane_stride_b,
+                             sum_img ? (unsigned)p.in_sum.plane_stride_b + plane_bytes : 0u);
+        else
+            return make_rsrc(sum_img + (long long)s * p.in_sum.plane_stride_b, sum_img ? plane_bytes : 0u);
+    };
+    constexpr unsigned kOobF32 = 0xFFFFFF00u;  // out of range, and still so 16 bytes further
+    // f32 trunk: per-lane offset of this lane's pixel in the two-plane window of a stage
+    auto x_offset = [&](const int q) {
+        const unsigned a = aoff[q];
+        return a == SRMI_OOB_OFFSET ? kOobF32 : (a & ~31u) + ((a >> 4) & 1u) * (unsigned)p.in.plane_stride_b;
+    };
+    auto s_offset = [&](const int q) {
+        const unsigned a = aoff[q];
+        return (a & ~31u) + ((a >> 4) & 1u) * (unsigned)p.in_sum.plane_stride_b;
+    };
     auto w1_rsrc = [&](int s) { return make_rsrc(p.wpk + (size_t)s * G::W_BYTES, G::W_BYTES); };
     auto w2_rsrc = [&](int s) { return make_rsrc(p.wpk2 + (size_t)s * G::W_BYTES, G::W_BYTES); };
     // weight piece i of this wave into `slot`; a wave without a piece in its last round repeats its previous one
@@ -146,10 +171,16 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
                                                  kk * 1024 + lane * 16, 0, 0, 0);
     };
 
-    u32x4 gx[G::APW], gt[G::APW];
+    u32x4 gx[G::APW], gt[G::APW], gx1[XF32 ? G::APW : 1];
     auto gate_fetch = [&](const int q, const bool really, const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rt) {
         const unsigned off = really ? aoff[q] : SRMI_OOB_OFFSET;
-        gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+        if constexpr (XF32) {
+            const unsigned xo = really ? x_offset(q) : kOobF32;
+            gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, xo, 0, 0));
+            gx1[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, xo + 16u, 0, 0));
+        } else {
+            gx[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+        }
         gt[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, off, 0, 0));
     };
     // One STEP combines one channel of one piece (8 steps per piece); the last step of a piece writes its 16 bytes to
@@ -174,8 +205,14 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
             gg1 = *(const f32x4*)(g + 4);
         }
         const float tv = (float)__builtin_bit_cast(f16x8, gt[q])[j];
-        const float xv = (float)__builtin_bit_cast(f16x8, gx[q])[j];
+        float xv;
+        if constexpr (XF32) xv = __uint_as_float(j < 4 ? gx[q][j & 3] : gx1[q][j & 3]);
+        else xv = (float)__builtin_bit_cast(f16x8, gx[q])[j];
         const float o = (tv * (j < 4 ? gg0[j & 3] : gg1[j & 3])) * gate_alpha + xv;
+        if constexpr (XF32) {  // the single-precision sum takes the place of x until it is stored
+            if (j < 4) gx[q][j & 3] = __float_as_uint(o);
+            else gx1[q][j & 3] = __float_as_uint(o);
+        }
         if (j & 1) {
             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
             const f16x2 h = {to_f16_sat(gprev), to_f16_sat(o)};
@@ -187,11 +224,17 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
             char* dst = mine ? xbuf + k * 1024 : smem + G::SPARE_OFF;
             *(u32x4*)(dst + lane * 16) = gpk;
             const bool store = live && ((keep >> q) & 1u);
-            __builtin_amdgcn_raw_buffer_store_b128(gpk, rx, store ? aoff[q] : SRMI_OOB_OFFSET, 0, 0);
+            if constexpr (XF32) {
+                const unsigned so = store ? s_offset(q) : kOobF32;
+                __builtin_amdgcn_raw_buffer_store_b128(gx[q], rx, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(gx1[q], rx, so + 16u, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(gpk, rx, store ? aoff[q] : SRMI_OOB_OFFSET, 0, 0);
+            }
             gate_fetch(q, fetch_next, ra_next, rt_next);
         }
     };
-    constexpr int kGateYounger = 3 * G::APW;   // per pixel piece: the in_sum store and the two loads of the next fetch
+    constexpr int kGateYounger = (XF32 ? 5 : 3) * G::APW;   // per pixel piece: the in_sum store(s) and the loads of the next fetch
 
     // ---- conv1: per-lane LDS addresses of its three pixel blocks -------------------------------------------
     int xb[G::BLK_PER_WAVE];      // byte offset of patch pixel (r1, c1) = tap (0, 0) of the lane's pixel, within a stage slot
@@ -234,7 +277,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
         for (int q = 0; q < G::APW; ++q) gate_fetch(q, true, ra, rt);
     }
     STAMP();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::BPW + 2 * G::APW) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::BPW + (XF32 ? 3 : 2) * G::APW) : "memory");
     if (tid < nstage * 16) ((float*)(smem + G::GATE_OFF))[tid] = gate_v;
     if (tid < 64) ((float*)(smem + G::BIAS1_OFF))[tid] = bias1_v;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -481,7 +524,8 @@ static int rcab_configure() {
     SRMI_HIP(hipGetDevice(&dev));
     const bool tracked = dev >= 0 && dev < 64;
     if (!tracked || !(configured.load(std::memory_order_acquire) >> dev & 1ull)) {
-        SRMI_HIP(hipFuncSetAttribute((const void*)rcab_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RcabGeom::LDS_BYTES));
+        SRMI_HIP(hipFuncSetAttribute((const void*)rcab_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RcabGeom::LDS_BYTES));
+        SRMI_HIP(hipFuncSetAttribute((const void*)rcab_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RcabGeom::LDS_BYTES));
         if (tracked) configured.fetch_or(1ull << dev, std::memory_order_release);
     }
     return 0;
@@ -498,11 +542,13 @@ extern "C" int srmi_rcab_fused(const srmi_rcab_desc_t* d, void* hip_stream) {
     if (d->dtype != SRMI_F16) SRMI_FAIL("srmi_rcab_fused: f16 compute only");
     if (d->c != 64) SRMI_FAIL("srmi_rcab_fused: the block must have 64 channels (got %d)", d->c);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0) SRMI_FAIL("srmi_rcab_fused: bad shape n=%d h=%d w=%d", d->n, d->h, d->w);
-    if (!d->in.ptr || d->in.dtype != SRMI_F16) SRMI_FAIL("srmi_rcab_fused: `in` must be an f16 tensor");
+    const bool xf32 = d->in.ptr && d->in.dtype == SRMI_F32;   // the residual trunk in single precision
+    if (!d->in.ptr || (d->in.dtype != SRMI_F16 && !xf32)) SRMI_FAIL("srmi_rcab_fused: `in` must be an f16 tensor, or an f32 one with a gated input");
     if (!d->in_gate.ptr || d->in_gate.dtype != SRMI_F16 || !d->gate) SRMI_FAIL("srmi_rcab_fused: in_gate (f16) and gate are required "
                                                                                  "(pass in_gate = in with gate_alpha 0 for a plain input)");
-    if (d->in_sum.ptr && (d->in_sum.dtype != SRMI_F16 || d->in_sum.ptr == d->in.ptr || d->in_sum.ptr == d->in_gate.ptr))
-        SRMI_FAIL("srmi_rcab_fused: in_sum must be a separate f16 tensor");
+    if (d->in_sum.ptr && (d->in_sum.dtype != d->in.dtype || d->in_sum.ptr == d->in.ptr || d->in_sum.ptr == d->in_gate.ptr))
+        SRMI_FAIL("srmi_rcab_fused: in_sum must be a separate tensor of the type of `in`");
+    if (xf32 && (long long)d->h * d->w * kPixBytes * 2 >= (1ll << 32)) SRMI_FAIL("srmi_rcab_fused: an f32 `in` needs planes below 2 GiB");
     if (!d->w1 || !d->b1 || !d->w2 || !d->b2) SRMI_FAIL("srmi_rcab_fused: missing weights or bias");
     if (!d->out.ptr || d->out.ptr == d->in_gate.ptr || d->out.ptr == d->in.ptr)
         SRMI_FAIL("srmi_rcab_fused: `out` must be a tensor of its own (other workgroups still read in / in_gate)");
@@ -537,7 +583,8 @@ extern "C" int srmi_rcab_fused(const srmi_rcab_desc_t* d, void* hip_stream) {
 #endif
     if (rcab_configure()) return -1;
     dim3 grid(p.tiles_x * p.tiles_y, 1, p.n);
-    hipLaunchKernelGGL(rcab_fused_kernel, grid, dim3(64 * kNW), RcabGeom::LDS_BYTES, (hipStream_t)hip_stream, p);
+    if (xf32) hipLaunchKernelGGL(rcab_fused_kernel<true>, grid, dim3(64 * kNW), RcabGeom::LDS_BYTES, (hipStream_t)hip_stream, p);
+    else hipLaunchKernelGGL(rcab_fused_kernel<false>, grid, dim3(64 * kNW), RcabGeom::LDS_BYTES, (hipStream_t)hip_stream, p);
     SRMI_HIP(hipGetLastError());
     return 0;
 }

@@ -82,8 +82,7 @@ static int load_model_body(FILE* f, long file_size, const char* path, int want_a
     d.n_groups = hdr[4]; d.grow_ch = hdr[5]; d.reduction = hdr[6]; d.with_meanshift = hdr[7];
     d.res_scale = res_scale;
     d.dtype = env_dtype();
-    // SRMI_TRUNK_F32=0: the residual trunk in the compute type instead of an f32 copy beside it (faster; RCAN then runs its
-    // blocks as one kernel each)
+    // SRMI_TRUNK_F32=0: the residual trunk in the compute type instead of an f32 copy beside it (faster)
     const char* tf = getenv("SRMI_TRUNK_F32");
     d.trunk_f32 = !(tf && !strcmp(tf, "0"));
     d.device = device;

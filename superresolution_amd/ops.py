@@ -210,7 +210,9 @@ def rcab_fused(x: Planes, pc1: PackedConv, pc2: PackedConv, *, in_gate: Planes =
     in_gate the block's input is x itself.  attention: (w1, b1, w2, b2) of the CALayer -> also returns scale[n][c]."""
     n, c, h, w = x.n, x.c, x.h, x.w
     d = _lib.RcabDesc()
-    d.dtype, d.n, d.h, d.w, d.c = x.dtype, n, h, w, c
+    # compute type: the body tensor's (x may be the f32 residual trunk when the input is gated)
+    cdt = in_gate.dtype if in_gate is not None else x.dtype
+    d.dtype, d.n, d.h, d.w, d.c = cdt, n, h, w, c
     d.inp = x.view()
     keep = [x, pc1, pc2, in_gate, gate, in_sum]
     if in_gate is not None:
@@ -222,7 +224,7 @@ def rcab_fused(x: Planes, pc1: PackedConv, pc2: PackedConv, *, in_gate: Planes =
         d.in_gate, d.gate, d.gate_alpha = x.view(), zeros.data_ptr(), 0.0
     d.w1, d.b1, d.w2, d.b2 = pc1.w.data_ptr(), pc1.b.data_ptr(), pc2.w.data_ptr(), pc2.b.data_ptr()
     if out is None:
-        out = Planes(n, c, h, w, x.dtype)
+        out = Planes(n, c, h, w, cdt)
     d.out = out.view()
     att_scale = None
     if attention is not None:

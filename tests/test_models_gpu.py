@@ -168,15 +168,16 @@ def test_rcan_configuration_full_size_frame():
     for trunk_f32 in (False, True):
         m2, _ = H.build_model(meta, "f16", trunk_f32=trunk_f32)
         eng = m2.engine()
-        if not trunk_f32:
-            # With an f16 trunk the default is the one-kernel block (both convolutions of a block in one launch):
-            # checked against the oracle here; its pooled sums see other tile shapes than the two-launch form, so the
-            # byte identity below is asserted between the two forms of the two-launch path.
-            one_kernel = eng.forward_u8(frames, _lib.ROUND_HALF_UP).cpu().numpy()
-            d1 = np.abs(one_kernel[0].astype(np.int32) - ref.astype(np.int32))
-            print(f"rcan 510x339 f16, one-kernel blocks: max u8 diff {d1.max()}, PSNR {O.psnr_u8(one_kernel[0], ref):.2f} dB")
-            assert eng.fused_rcab() and d1.max() <= 1 and O.psnr_u8(one_kernel[0], ref) >= 50.0
-            eng.set_fused_rcab(False)
+        # The default is the one-kernel block (both convolutions of a block in one launch), with either trunk: checked
+        # against the oracle here; its pooled sums see other tile shapes than the two-launch form, so the byte identity
+        # below is asserted between the two forms of the two-launch path.
+        one_kernel = eng.forward_u8(frames, _lib.ROUND_HALF_UP).cpu().numpy()
+        d1 = np.abs(one_kernel[0].astype(np.int32) - ref.astype(np.int32))
+        print(f"rcan 510x339 f16 trunk_f32={trunk_f32}, one-kernel blocks: max u8 diff {d1.max()}, PSNR {O.psnr_u8(one_kernel[0], ref):.2f} dB")
+        assert eng.fused_rcab() and d1.max() <= 1 and O.psnr_u8(one_kernel[0], ref) >= 50.0
+        if trunk_f32:
+            assert np.array_equal(one_kernel[0], got)      # the module's own forward ran this plan
+        eng.set_fused_rcab(False)
         fused = eng.forward_u8(frames, _lib.ROUND_HALF_UP).cpu().numpy()
         eng.set_fused_attention(False)
         plain = eng.forward_u8(frames, _lib.ROUND_HALF_UP).cpu().numpy()
@@ -184,8 +185,6 @@ def test_rcan_configuration_full_size_frame():
         diff = np.abs(fused[0].astype(np.int32) - ref.astype(np.int32))
         print(f"rcan 510x339 f16 trunk_f32={trunk_f32}: max u8 diff {diff.max()}, PSNR {O.psnr_u8(fused[0], ref):.2f} dB")
         assert diff.max() <= 1 and O.psnr_u8(fused[0], ref) >= 50.0
-        if trunk_f32:
-            assert np.array_equal(fused[0], got)
 
 
 def test_1080p_frame_whole_and_halo_tiled():

@@ -74,6 +74,32 @@ def test_one_kernel_block_equals_the_two_launch_form(n, h, w, gated):
     assert float((scale_one.cpu() - sref).abs().max()) <= 2e-3
 
 
+@pytest.mark.parametrize("n,h,w", [(1, 8, 32), (2, 37, 53), (1, 5, 7), (1, 41, 97)])
+def test_one_kernel_block_with_an_f32_trunk_equals_the_two_launch_form(n, h, w):
+    """`in` and in_sum as f32 tensors (the residual trunk kept in single precision): the stored block input (f32) and
+    the block body bit for bit those of srmi_conv3x3's gated f32 input followed by the second convolution."""
+    x, yp, g, (w1, b1), (w2, b2), att = _block(21, n, h, w)
+    x = x + rnd("xlo", (n, 64, h, w), 77, 2.0 ** -13)          # bits below f16 precision: the trunk really is f32
+    pc1 = ops.PackedConv(w1.numpy(), b1.numpy(), _lib.F16, cout_tile=64)
+    pc2 = ops.PackedConv(w2.numpy(), b2.numpy(), _lib.F16, cout_tile=64)
+    X, Y = ops.Planes.from_nchw(x, _lib.F32), ops.Planes.from_nchw(yp, _lib.F16)
+    alpha = 0.7
+    s_two, s_one = ops.Planes(n, 64, h, w, _lib.F32, zero=True), ops.Planes(n, 64, h, w, _lib.F32, zero=True)
+    t = ops.conv3x3(X, pc1, act=_lib.ACT_RELU, rows_per_wave=2, in_gate=Y, gate=g, gate_alpha=alpha, in_sum=s_two)
+    one, scale_one = ops.rcab_fused(X, pc1, pc2, in_gate=Y, gate=g, gate_alpha=alpha, in_sum=s_one, attention=att)
+    assert one.dtype == _lib.F16
+    assert torch.equal(s_one.to_nchw().cpu(), s_two.to_nchw().cpu()), "stored block input differs"
+    want = yp * g.cpu()[:, :, None, None] * alpha + x
+    assert float((s_one.to_nchw().cpu() - want).abs().max()) <= 2.0 ** -22 * float(want.abs().max())
+    two, scale_two = ops.conv3x3(t, pc2, rows_per_wave=2, attention=att)
+    a, b = one.to_nchw().cpu(), two.to_nchw().cpu()
+    assert torch.equal(a, b), f"block body differs: max {float((a - b).abs().max()):.3e}"
+    assert float((scale_one - scale_two).abs().max()) <= 2e-6
+    # an f32 `in` needs the gated form (a plain input is the trunk's f16 copy)
+    with pytest.raises(_lib.SrmiError):
+        ops.rcab_fused(X, pc1, pc2)
+
+
 def test_one_kernel_block_rejects_what_it_does_not_cover():
     x = ops.Planes(1, 128, 16, 16, _lib.F16, zero=True)
     pc = ops.PackedConv(np.zeros((128, 128, 3, 3), np.float32), None, _lib.F16, cout_tile=64)
@@ -109,3 +135,26 @@ def test_rcan_with_one_kernel_blocks_against_the_oracle():
     many = eng.forward_u8(batch, _lib.ROUND_HALF_UP).cpu().numpy()
     for i in range(6):
         assert np.array_equal(many[i], outs[True][i % 2]), i
+
+
+def test_rcan_with_an_f32_trunk_runs_one_kernel_blocks():
+    """The modules' and runners' default (f16 operands, f32 residual trunk) also runs its blocks as one kernel each:
+    within the bound of the oracle, and next to the two-launch plan's bytes (block bodies are bit-identical; the pooled
+    means are summed over other tile shapes, so an attention scale may differ in its last f32 bit and a byte of the
+    output with it)."""
+    meta = dict(arch="rcan", scale=2, n_resgroups=2, n_resblocks=3, seed=95, input="range")
+    model, sd = H.build_model(meta, "f16", trunk_f32=True)
+    eng = model.engine()
+    assert eng.fused_rcab()
+    imgs = np.stack([synth.smooth_image(45, 67, 96), synth.random_image(45, 67, 97)])
+    with torch.no_grad():
+        ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(imgs)), O.ROUND_HALF_UP)
+    one = model.forward_u8(imgs, _lib.ROUND_HALF_UP).numpy()
+    eng.set_fused_rcab(False)
+    two = model.forward_u8(imgs, _lib.ROUND_HALF_UP).numpy()
+    d12 = np.abs(one.astype(np.int32) - two.astype(np.int32))
+    # (measured: 0.18 % of the bytes differ, by one: scales that differ by 1e-6 move values of order 100 by 1e-4 per block)
+    assert d12.max() <= 1 and (d12 != 0).mean() < 1e-2, (d12.max(), (d12 != 0).mean())
+    for got in (one, two):
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and O.psnr_u8(got, ref) >= 50.0
