@@ -553,7 +553,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.model, args.dtype),
                          "mfma_busy": pmc_record(args.model, args.dtype).get("mfma_busy"),
-                         "kernel": "conv3x3_kernel<dtype,rows,cout_blocks> (all instantiations; "
+                         "kernel": ("rcab_fused_kernel (one launch per block, counted as its two convolutions) and "
+                                    if args.model == "rcan" and args.dtype == "f16" and eng.fused_rcab() else "") +
+                                   "conv3x3_kernel<dtype,rows,cout_blocks> (all instantiations; "
                                    f"{flops_frame / 1e12:.3f} algorithmic TFLOP per frame over HIP-event device time)",
                          "launches_per_frame": launches,
                          "flops_per_launch": round(flops_frame / launches),
