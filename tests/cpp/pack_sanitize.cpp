@@ -52,6 +52,29 @@ int main() {
             ++done;
         }
     }
+    // the two Winograd forms of the dense-block convolutions (f16 images [tile][stage][position][half][32][8 halves])
+    for (const Case& c : cases) {
+        if (c.cin % 16 || c.ps_r != 1 || c.tile != 32) continue;
+        for (int form = 0; form < 2; ++form) {
+            int nbias = 0;
+            const size_t bytes = form ? srmi_pack_wino1d3x3_bytes(c.cout, c.cin, &nbias) : srmi_pack_wino3x3_bytes(c.cout, c.cin, &nbias);
+            if (!bytes || nbias < c.cout) { fprintf(stderr, "bad Winograd sizes for cout %d cin %d\n", c.cout, c.cin); return 1; }
+            std::vector<float> w((size_t)c.cout * c.cin * 9), b((size_t)c.cout, 0.25f);
+            uint32_t s = 7654321u + (uint32_t)done;
+            for (auto& v : w) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
+            std::vector<unsigned char> img(bytes, 0xCD), img2(bytes, 0x37);
+            std::vector<float> bias((size_t)nbias, -777.0f), bias2((size_t)nbias, -777.0f);
+            auto pack = form ? srmi_pack_wino1d3x3 : srmi_pack_wino3x3;
+            if (pack(c.cout, c.cin, w.data(), b.data(), img.data(), bias.data()) || pack(c.cout, c.cin, w.data(), nullptr, img2.data(), bias2.data())) {
+                fprintf(stderr, "Winograd pack failed: %s\n", srmi_last_error());
+                return 1;
+            }
+            if (memcmp(img.data(), img2.data(), bytes)) { fprintf(stderr, "Winograd image (form %d, cout %d, cin %d) has unwritten bytes\n", form, c.cout, c.cin); return 1; }
+            for (int i = 0; i < nbias; ++i)
+                if (bias[i] == -777.0f || bias2[i] != 0.f) { fprintf(stderr, "Winograd bias %d not written\n", i); return 1; }
+            ++done;
+        }
+    }
     // rejected shapes return -1 with a message and write nothing
     unsigned char dummy[64];
     float fb[64];

@@ -204,6 +204,39 @@ def test_weight_packing_layout_and_rounding():
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_winograd_weight_packing_layout():
+    """srmi_pack_wino3x3 / srmi_pack_wino1d3x3 against a numpy restatement: U = G g G^T (both axes) and U = g G^T (along
+    x only) per channel pair, computed in double precision, rounded once to f16, in the documented LDS images
+    [cout tile][16-channel stage][position][channel half][cout row 32][8 halves]; rows beyond cout are zero."""
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    for cout, cin in ((32, 32), (48, 64), (64, 16)):
+        w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        ntile, nstage = (cout + 31) // 32, cin // 16
+        wpad = np.zeros((ntile * 32, cin, 3, 3), np.float64)
+        wpad[:cout] = w
+        for fn_bytes, fn, npos, U in (
+                (L.srmi_pack_wino3x3_bytes, L.srmi_pack_wino3x3, 16, np.einsum("ak,ockl,bl->ocab", G, wpad, G).reshape(ntile * 32, cin, 16)),
+                (L.srmi_pack_wino1d3x3_bytes, L.srmi_pack_wino1d3x3, 12, np.einsum("ockl,bl->ockb", wpad, G).reshape(ntile * 32, cin, 12))):
+            nb = C.c_int(0)
+            fn_bytes.restype = C.c_size_t
+            nbytes = fn_bytes(cout, cin, C.byref(nb))
+            assert nbytes == ntile * nstage * npos * 32 * 32 and nb.value == ntile * 32
+            wp = np.full(nbytes // 2, 0x7e00, np.uint16)
+            bp = np.full(nb.value, np.nan, np.float32)
+            assert fn(cout, cin, w.ctypes.data, b.ctypes.data, wp.ctypes.data, bp.ctypes.data) == 0
+            got = wp.view(np.float16).reshape(ntile, nstage, npos, 2, 32, 8)
+            # want[t][st][pos][c][row][e] = U[32 t + row][16 st + 8 c + e][pos]
+            want = U.reshape(ntile, 32, nstage, 2, 8, npos).transpose(0, 2, 5, 3, 1, 4).astype(np.float32).astype(np.float16)
+            assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+            assert np.array_equal(bp[:cout], b) and not bp[cout:].any()
+    assert L.srmi_pack_wino3x3_bytes(32, 24, None) == 0 and L.srmi_pack_wino1d3x3_bytes(32, 24, None) == 0
+    wp = np.zeros(16, np.uint16)
+    assert L.srmi_pack_wino3x3(32, 24, w.ctypes.data, None, wp.ctypes.data, bp.ctypes.data) == -1
+
+
 def test_forward_without_gpu_fails_loudly():
     m = realesrgan_model.RRDBNet(num_block=1)
     with pytest.raises(_lib.SrmiError, match="no HIP device"):
