@@ -42,6 +42,11 @@ def build_model(arch, dtype, trunk_f32, device, growth_round8=True):
     elif arch == "edsr":
         m = EDSR(compute_dtype=dtype, trunk_f32=trunk_f32, device=device)
         sd = synth.edsr_state_dict(seed=0)
+    elif arch == "edsr_baseline":
+        # the 16-block, 64-feature EDSR (1.5 M parameters) that the baseline's first configuration describes; the
+        # reference's constructor defaults are the 32 x 256 network above
+        m = EDSR(n_resblocks=16, n_feats=64, compute_dtype=dtype, trunk_f32=trunk_f32, device=device)
+        sd = synth.edsr_state_dict(n_resblocks=16, n_feats=64, seed=0)
     elif arch == "rcan":
         m = RCAN(scale=4, compute_dtype=dtype, trunk_f32=trunk_f32, device=device)
         sd = synth.rcan_state_dict(seed=0)
@@ -72,6 +77,8 @@ def cpu_baseline(arch, sd, h, w, threads):
                 return O.post_unit(O.rrdbnet_forward(sd, O.pre_unit(img)), O.ROUND_HALF_UP)
             if arch == "edsr":
                 return O.post_range(O.edsr_forward(sd, O.pre_raw(img)), O.ROUND_HALF_UP)
+            if arch == "edsr_baseline":
+                return O.post_range(O.edsr_forward(sd, O.pre_raw(img), n_resblocks=16), O.ROUND_HALF_UP)
             return O.post_range(O.rcan_forward(sd, O.pre_raw(img)), O.ROUND_HALF_UP)
 
     run()  # warm-up
@@ -593,6 +600,8 @@ def main():
             rec["other_configs"] = {
                 "edsr_x4_256x256_batch32_f16": side_config("edsr", "f16", 256, 256, 32, side_steps, local_rank, cpu=edsr_cpu),
                 "edsr_x4_256x256_batch32_bf16": side_config("edsr", "bf16", 256, 256, 32, side_steps, local_rank, cpu=edsr_cpu),
+                "edsr_baseline_16x64_x4_256x256_batch32_f16": side_config("edsr_baseline", "f16", 256, 256, 32, 5 * side_steps, local_rank,
+                                                                           cpu={} if with_cpu else None),
                 "rcan_x4_510x339_f16": side_config("rcan", "f16", 339, 510, 12, side_steps, local_rank,
                                                    cpu={} if with_cpu else None),
                 "rrdbnet_x4_510x339_w8a8": w8a8_config(339, 510, 12, side_steps, local_rank,

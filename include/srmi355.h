@@ -400,9 +400,10 @@ int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep);
  * output form it while loading (srmi_conv3x3's gated input) instead of a separate srmi_ca_apply pass over the
  * image; 0 keeps the separate pass.  Both give the same bytes. */
 int srmi_model_set_fused_attention(srmi_model_t* m, int on);
-/* RCAN, f16 compute with an f16 trunk and 64 features: 1 runs both convolutions of every block in one kernel
- * (srmi_rcab_fused: the tensor between them never leaves the chip), 0 as two srmi_conv3x3 launches.  Needs the fused
- * attention above.  Both forms stay within the half-precision parity bound; see srmi_model_get_fused_rcab for the default. */
+/* RCAN and EDSR with f16 compute and 64 features (trunk in f16, or in f32 beside it): 1 runs both convolutions of every
+ * block in one kernel (srmi_rcab_fused: the tensor between them never leaves the chip), 0 as two srmi_conv3x3 launches.
+ * RCAN needs the fused attention above; in EDSR the block's residual add moves into the consumer's gated input (gate
+ * vector of ones).  Both forms stay within the half-precision parity bound; see srmi_model_get_fused_rcab for the default. */
 int srmi_model_set_fused_rcab(srmi_model_t* m, int on);
 int srmi_model_get_fused_rcab(const srmi_model_t* m);
 /* Internal HIP streams (1..4, default 3) over which the sweeps of one forward call are spread.

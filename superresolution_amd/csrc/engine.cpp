@@ -94,7 +94,7 @@ struct srmi_model {
     size_t ws_bytes = 0;
     int sweep = 1;
     bool fuse_attention = true;  // RCAN, half-precision trunk: attention output formed by the consuming conv
-    bool fuse_rcab = true;       // RCAN, f16 trunk, 64 features: both convolutions of a block in one kernel (srmi_rcab_fused)
+    bool fuse_rcab = true;       // RCAN / EDSR, f16 operands, 64 features: both convolutions of a block in one kernel (srmi_rcab_fused)
     int mb_override = 0;
     // RRDBNet, f16: the grown channels x1..x4 of every dense block (and the weights that multiply them)
     // carry 8 significant bits; the trunk keeps full f16 precision (see srmi_model_set_growth_round8)
@@ -443,7 +443,7 @@ struct Exec {
     // both convolutions of a residual channel-attention block in one launch (srmi_rcab_fused); gate == nullptr: the
     // block's input is the plain tensor `in`
     int rcab(const char* name1, const char* name2, const srmi_tensor_t& in, int h, int w, const Gate* gate,
-             const float* finite_floats, const srmi_tensor_t& out, const Attention& att) {
+             const float* finite_floats, const srmi_tensor_t& out, const Attention* att) {
         auto i1 = m->convs.find(std::string_view(name1));
         auto i2 = m->convs.find(std::string_view(name2));
         if (i1 == m->convs.end() || i2 == m->convs.end()) SRMI_FAIL("internal: convs '%s' / '%s' not uploaded", name1, name2);
@@ -460,8 +460,10 @@ struct Exec {
         r.w1 = i1->second.wpk; r.b1 = i1->second.bias;
         r.w2 = i2->second.wpk; r.b2 = i2->second.bias;
         r.out = out;
-        r.ca.sums = att.sums; r.ca.count = att.count; r.ca.scale = att.scale; r.ca.cr = att.cr;
-        r.ca.w1 = att.w->w1; r.ca.b1 = att.w->b1; r.ca.w2 = att.w->w2; r.ca.b2 = att.w->b2;
+        if (att) {
+            r.ca.sums = att->sums; r.ca.count = att->count; r.ca.scale = att->scale; r.ca.cr = att->cr;
+            r.ca.w1 = att->w->w1; r.ca.b1 = att->w->b1; r.ca.w2 = att->w->w2; r.ca.b2 = att->w->b2;
+        }
         return srmi_rcab_fused(&r, stream);
     }
 
@@ -793,11 +795,54 @@ static int run_edsr(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
     const auto& d = m->d;
     const int nf = d.n_feats, T = m->cdt(), TR = m->tdt();
     const bool split = m->split_trunk();
+    // 64 features, f16 operands (the EDSR-baseline family): conv -> ReLU -> conv of a ResBlock (edsr_model.py:44-47) as
+    // one kernel with the tensor between them in LDS (srmi_rcab_fused without its attention tail).  A block's output
+    // x + res_scale * y is then never written by a pass of its own: the next block (or body.N) forms it while loading,
+    // with a gate vector of ones, and stores it to the next trunk buffer on the way.
+    const bool one_kernel = m->fuse_rcab && T == SRMI_F16 && (!split || TR == SRMI_F32) && nf == 64 && !m->mb_override &&
+                            d.n_blocks > 0;
     Buf XT[2] = {A.take(nf, h, w, T), A.take(nf, h, w, T)};
     Buf XR[2];
     if (split) { XR[0] = A.take(nf, h, w, TR); XR[1] = A.take(nf, h, w, TR); }
     Buf Tm = A.take(nf, h, w, T);
     Buf H = A.take(nf, h, w, TR);
+    Buf Yb[2];
+    float* ones = nullptr;
+    if (one_kernel) {
+        Yb[0] = A.take(nf, h, w, T);
+        Yb[1] = A.take(nf, h, w, T);
+        ones = A.take_floats((size_t)A.ns * nf);
+    }
+    if (ex && one_kernel) {
+        SRMI_HIP(hipMemsetD32Async((hipDeviceptr_t)ones, 0x3f800000, (size_t)A.ns * nf, ex->stream));   // 1.0f
+        srmi_tensor_t o = tv(XT[0]), o2 = tv(H);
+        if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
+        char name[64], name2[64];
+        int k = 0, kr = 0, yk = 0;
+        bool trunk_in_xr = false;
+        // the trunk before the pending block: the compute-dtype copy, or (split) the f32 one (the head's output at first)
+        auto trunk_view = [&]() { return !split ? tv(XT[k]) : (trunk_in_xr ? tv(XR[kr]) : tv(H)); };
+        for (int i = 0; i < d.n_blocks; ++i) {
+            snprintf(name, sizeof(name), "body.%d.body.0", i);
+            snprintf(name2, sizeof(name2), "body.%d.body.2", i);
+            const bool pending = i > 0;
+            const srmi_tensor_t in = pending ? trunk_view() : tv(XT[k]);
+            const Exec::Gate gate{tv(Yb[yk]), ones, d.res_scale, split ? tv(XR[kr ^ 1]) : tv(XT[k ^ 1])};
+            if (ex->rcab(name, name2, in, h, w, pending ? &gate : nullptr, ones, tv(Yb[yk ^ 1]), nullptr)) return -1;
+            if (pending) {
+                if (split) { kr ^= 1; trunk_in_xr = true; }
+                else k ^= 1;
+            }
+            yk ^= 1;
+        }
+        // body.N consumes the last block's output the same way and adds the head's output (edsr_model.py:119-121)
+        snprintf(name, sizeof(name), "body.%d", d.n_blocks);
+        const srmi_tensor_t in = trunk_view(), res = tv(H), o1 = tv(XT[k ^ 1]);
+        const Exec::Gate gate{tv(Yb[yk]), ones, d.res_scale, srmi_tensor_t{}};
+        if (ex->conv(name, in, h, w, SRMI_ACT_NONE, false, 1.f, &res, 1.f, nullptr, &o1, nullptr, nullptr,
+                     gate_rows_per_wave(m, h), &gate)) return -1;
+        return run_tail_stages(m, A, ex, io, XT[k ^ 1], h, w);
+    }
     if (ex) {
         srmi_tensor_t o = tv(XT[0]), o2 = tv(H);
         if (ex->first(io->in, io->in_kind, h, w, io->pre_mat, io->pre_bias, &o, &o2)) return -1;
@@ -878,7 +923,7 @@ static int run_rcan(srmi_model* m, Arena& A, Exec* ex, const IoSpec* io, int h, 
                     // trunk (in its own precision) and the previous block's body, and store it on the way
                     const srmi_tensor_t in = pending ? trunk_view() : tv(XT[k]);
                     const Exec::Gate gate{tv(Yb[yk]), scale, d.res_scale, split ? tv(XR[kr ^ 1]) : tv(XT[k ^ 1])};
-                    if (ex->rcab(name, name2, in, h, w, pending ? &gate : nullptr, scale, tv(Yb[yk ^ 1]), att)) return -1;
+                    if (ex->rcab(name, name2, in, h, w, pending ? &gate : nullptr, scale, tv(Yb[yk ^ 1]), &att)) return -1;
                     if (pending) {
                         if (split) { kr ^= 1; trunk_in_xr = true; }
                         else k ^= 1;

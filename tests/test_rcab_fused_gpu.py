@@ -158,3 +158,34 @@ def test_rcan_with_an_f32_trunk_runs_one_kernel_blocks():
     for got in (one, two):
         d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
         assert d.max() <= 1 and O.psnr_u8(got, ref) >= 50.0
+
+
+@pytest.mark.parametrize("trunk_f32", [False, True])
+def test_edsr_with_64_features_runs_its_resblocks_as_one_kernel_each(trunk_f32):
+    """The EDSR-baseline family (64 features; here 16 blocks, x4; the synthetic weights' gains are made for the
+    reference's default res_scale 0.1): conv -> ReLU -> conv of a ResBlock (edsr_model.py:44-47) in one launch, the
+    residual add left to the consumer's gated input with a gate vector of ones.  Within the half-precision bound of the
+    oracle like the two-launch plan, and next to its bytes (the block output is formed from the f16-rounded body instead
+    of the f32 accumulator)."""
+    meta = dict(arch="edsr", n_resblocks=16, n_feats=64, scale=4, seed=97, input="range")
+    model, sd = H.build_model(meta, "f16", trunk_f32=trunk_f32)
+    eng = model.engine()
+    assert eng.fused_rcab()
+    imgs = np.stack([synth.smooth_image(61, 83, 98), synth.random_image(61, 83, 99)])
+    with torch.no_grad():
+        ref = O.post_range(H.oracle_forward(meta, sd, O.pre_raw(imgs)), O.ROUND_HALF_UP)
+    outs = {}
+    for on in (True, False):
+        eng.set_fused_rcab(on)
+        got = model.forward_u8(imgs, _lib.ROUND_HALF_UP).numpy()
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        print(f"edsr 16x64 trunk_f32={trunk_f32} one-kernel blocks={on}: max u8 diff {d.max()}, PSNR {O.psnr_u8(got, ref):.2f} dB")
+        assert d.max() <= 1 and O.psnr_u8(got, ref) >= 50.0
+        outs[on] = got
+    d12 = np.abs(outs[True].astype(np.int32) - outs[False].astype(np.int32))
+    assert d12.max() <= 1
+    eng.set_fused_rcab(True)
+    batch = torch.from_numpy(np.concatenate([imgs] * 3)).cuda()
+    many = eng.forward_u8(batch, _lib.ROUND_HALF_UP).cpu().numpy()
+    for i in range(6):
+        assert np.array_equal(many[i], outs[True][i % 2]), i
