@@ -1,5 +1,6 @@
 """srmi_model_forward_u8_noalloc under HIP graph capture: the call is captured into a graph on a side stream, the
-graph is replayed on new input bytes, and every replay gives the bytes srmi_model_forward_u8 gives."""
+graph is replayed on new input bytes, and every replay gives the bytes srmi_model_forward_u8 gives (RCAN and the
+64-feature EDSR with their one-kernel blocks and the memset nodes those plans start with)."""
 import ctypes as C
 
 import pytest
@@ -12,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("meta", [dict(arch="rrdbnet", num_block=2, scale=4, seed=51, input="unit"),
-                                  dict(arch="rcan", scale=2, n_resgroups=1, n_resblocks=2, seed=52, input="raw")],
+                                  dict(arch="rcan", scale=2, n_resgroups=1, n_resblocks=2, seed=52, input="raw"),
+                                  dict(arch="edsr", scale=2, n_resblocks=3, n_feats=64, seed=53, input="raw")],
                          ids=lambda m: m["arch"])
 def test_noalloc_call_can_be_captured_and_replayed(meta):
     L = _lib.lib()
