@@ -84,8 +84,8 @@ class Engine:
         check(lib().srmi_model_set_fused_attention(self._h, int(bool(on))), "srmi_model_set_fused_attention")
 
     def set_fused_rcab(self, on=True):
-        """RCAN, f16 with an f16 trunk and 64 features: both convolutions of a block in one kernel (True) or as two
-        launches (False)."""
+        """RCAN and EDSR with f16 operands and 64 features (trunk in f16 or f32): both convolutions of a block in one
+        kernel (True) or as two launches (False)."""
         check(lib().srmi_model_set_fused_rcab(self._h, int(bool(on))), "srmi_model_set_fused_rcab")
 
     def fused_rcab(self):
