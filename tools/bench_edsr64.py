@@ -1,5 +1,7 @@
+"""EDSR-baseline (16 blocks x 64 features, x4) at 256x256, batch 36: one-kernel ResBlocks against two launches per block, with the
+trunk in f16 and in f32 (HIP-event time over 10 calls).  python tools/bench_edsr64.py"""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from superresolution_amd import EDSR, _lib, synth
 for trunk in (False, True):
