@@ -104,7 +104,9 @@ struct ConvGeom {
     static constexpr int MIN_WAVES = (MB == 2 && NB == 1 && kNW == 4) ? 4 : (kNW == 4 ? 2 : 4);
 };
 
-template <int DT, int MB, int NB, int GATE>
+// CARRIED: the main loop's form (below), chosen by the host from the number of stages: one kernel holds one form, so the
+// accumulators of the two loops never meet in copies (or spills) in front of the epilogue.
+template <int DT, int MB, int NB, int GATE, bool CARRIED = false>
 __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
     using G = ConvGeom<MB, NB>;
@@ -463,10 +465,8 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
 
     // Two main loops; long reductions take the first (measured: +3 % on EDSR's 16-stage layers, +1 % on
     // the 8-12-stage layers of a dense block, but -4 % on 4-stage layers, which keep the second).
-    constexpr int kCarriedMinStages = 8;
-    bool carried = false;
-    if constexpr (G::NS == 2 && !GATE) carried = nstage >= kCarriedMinStages;
-    if (carried) {
+    static_assert(!CARRIED || (G::NS == 2 && !GATE), "the fragment-carried loop: two-slot ring, plain input");
+    if constexpr (CARRIED) {
     // Fragment-carried pipeline (two-slot ring).  The barrier of a stage sits after the LAST LDS read
     // of the stage has returned, not after its last MFMA: the final third of the stage's MFMAs only
     // needs registers, so it runs behind the barrier, together with the first fragment reads of the
@@ -718,6 +718,11 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
 // ---- host launcher --------------------------------------------------------------------------------
 // The dynamic-LDS limit is a per-device attribute of the function: set once on every device used.  Setting
 // it twice is harmless, so concurrent first calls only need the bookkeeping itself to be atomic.
+// (a plain input on the two-slot ring has both loop forms: two kernels)
+template <int MB, int NB, int GATE>
+constexpr bool kHasCarried = !GATE && ConvGeom<MB, NB>::NS == 2;
+constexpr int kCarriedMinStages = 8;   // stages from which the fragment-carried loop is the faster one
+
 template <int DT, int MB, int NB, int GATE>
 static int configure() {
     static std::atomic<unsigned long long> configured{0};
@@ -725,8 +730,10 @@ static int configure() {
     SRMI_HIP(hipGetDevice(&dev));
     const bool tracked = dev >= 0 && dev < 64;
     if (!tracked || !(configured.load(std::memory_order_acquire) >> dev & 1ull)) {
-        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB, GATE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0)));
+        constexpr int lds = (int)ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0);
+        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB, GATE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (kHasCarried<MB, NB, GATE>)
+            SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB, GATE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if (tracked) configured.fetch_or(1ull << dev, std::memory_order_release);
     }
     return 0;
@@ -737,7 +744,14 @@ static int launch(const ConvParams& p, hipStream_t stream) {
     constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0);
     if (configure<DT, MB, NB, GATE>()) return -1;
     dim3 grid(p.tiles_x * p.tiles_y, p.cout / (32 * NB), p.n);
-    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB, GATE>), grid, dim3(64 * kNW), lds, stream, p);
+    if constexpr (kHasCarried<MB, NB, GATE>) {
+        if (p.ncb >= kCarriedMinStages) {
+            hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB, GATE, true>), grid, dim3(64 * kNW), lds, stream, p);
+            SRMI_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB, GATE, false>), grid, dim3(64 * kNW), lds, stream, p);
     SRMI_HIP(hipGetLastError());
     return 0;
 }
