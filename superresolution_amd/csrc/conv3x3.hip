@@ -676,29 +676,32 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
         // int8 dense blocks: grown channels go out as int8; the block's last conv adds the half-precision trunk
         // and writes the new trunk twice, quantised (next conv input) and in half precision (next residual)
         if (plain_io && rd == -1 && o2 == -1) {
-            epilogue<DT, MB, NB, DT, -1, false, -1>(p, ctx, acc, lds_bias, lds_red);
+            epilogue<DT, MB, NB, DT, -1, false, -1, 0, false>(p, ctx, acc, lds_bias, lds_red);
         } else if (plain_io && rd == SRMI_F16 && r2 == -1 && o2 == SRMI_F16) {
-            epilogue<DT, MB, NB, DT, SRMI_F16, false, SRMI_F16>(p, ctx, acc, lds_bias, lds_red);
+            epilogue<DT, MB, NB, DT, SRMI_F16, false, SRMI_F16, 0, false>(p, ctx, acc, lds_bias, lds_red);
         } else if (plain_io && rd == SRMI_F16 && r2 == SRMI_F16 && o2 == SRMI_F16) {
-            epilogue<DT, MB, NB, DT, SRMI_F16, true, SRMI_F16>(p, ctx, acc, lds_bias, lds_red);
+            epilogue<DT, MB, NB, DT, SRMI_F16, true, SRMI_F16, 0, false>(p, ctx, acc, lds_bias, lds_red);
         } else {
             epilogue<DT, MB, NB, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc, lds_bias, lds_red);
         }
     } else {
+    // (per-tile channel sums go with the plain arm or the generic one: the arms with residuals carry no sum registers)
+    const bool sums = p.chansum != nullptr || p.ca_sums != nullptr;
     if (plain_io && rd == -1 && o2 == -1) {
-        epilogue<DT, MB, NB, DT, -1, false, -1>(p, ctx, acc, lds_bias, lds_red);
-    } else if (plain_io && rd == SRMI_F32 && r2 == -1 && o2 == -1) {
-        epilogue<DT, MB, NB, DT, SRMI_F32, false, -1>(p, ctx, acc, lds_bias, lds_red);
-    } else if (plain_io && rd == SRMI_F32 && r2 == -1 && o2 == SRMI_F32) {
-        epilogue<DT, MB, NB, DT, SRMI_F32, false, SRMI_F32>(p, ctx, acc, lds_bias, lds_red);
-    } else if (plain_io && rd == SRMI_F32 && r2 == SRMI_F32 && o2 == SRMI_F32) {
-        epilogue<DT, MB, NB, DT, SRMI_F32, true, SRMI_F32>(p, ctx, acc, lds_bias, lds_red);
-    } else if (plain_io && rd == DT && r2 == -1 && o2 == -1) {
-        epilogue<DT, MB, NB, DT, DT, false, -1>(p, ctx, acc, lds_bias, lds_red);
-    } else if (plain_io && rd == DT && r2 == -1 && o2 == DT) {
-        epilogue<DT, MB, NB, DT, DT, false, DT>(p, ctx, acc, lds_bias, lds_red);
-    } else if (plain_io && rd == DT && r2 == DT && o2 == DT) {
-        epilogue<DT, MB, NB, DT, DT, true, DT>(p, ctx, acc, lds_bias, lds_red);
+        if (sums) epilogue<DT, MB, NB, DT, -1, false, -1, 0, true>(p, ctx, acc, lds_bias, lds_red);
+        else epilogue<DT, MB, NB, DT, -1, false, -1, 0, false>(p, ctx, acc, lds_bias, lds_red);
+    } else if (!sums && plain_io && rd == SRMI_F32 && r2 == -1 && o2 == -1) {
+        epilogue<DT, MB, NB, DT, SRMI_F32, false, -1, 0, false>(p, ctx, acc, lds_bias, lds_red);
+    } else if (!sums && plain_io && rd == SRMI_F32 && r2 == -1 && o2 == SRMI_F32) {
+        epilogue<DT, MB, NB, DT, SRMI_F32, false, SRMI_F32, 0, false>(p, ctx, acc, lds_bias, lds_red);
+    } else if (!sums && plain_io && rd == SRMI_F32 && r2 == SRMI_F32 && o2 == SRMI_F32) {
+        epilogue<DT, MB, NB, DT, SRMI_F32, true, SRMI_F32, 0, false>(p, ctx, acc, lds_bias, lds_red);
+    } else if (!sums && plain_io && rd == DT && r2 == -1 && o2 == -1) {
+        epilogue<DT, MB, NB, DT, DT, false, -1, 0, false>(p, ctx, acc, lds_bias, lds_red);
+    } else if (!sums && plain_io && rd == DT && r2 == -1 && o2 == DT) {
+        epilogue<DT, MB, NB, DT, DT, false, DT, 0, false>(p, ctx, acc, lds_bias, lds_red);
+    } else if (!sums && plain_io && rd == DT && r2 == DT && o2 == DT) {
+        epilogue<DT, MB, NB, DT, DT, true, DT, 0, false>(p, ctx, acc, lds_bias, lds_red);
     } else {
         epilogue<DT, MB, NB, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc, lds_bias, lds_red);
     }

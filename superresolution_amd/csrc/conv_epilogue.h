@@ -108,7 +108,9 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 //     rows x 16 tile columns;
 //   2 (F(2,3) along x): "row" r is pixel (row r >> 1, column r & 1) of the lane's pair of two-pixel tiles in the wave's
 //     two image rows; the wave's 32 tile columns span 64 pixels.
-template <int DT, int MB, int NB, int OUT, int RES, bool RES2, int OUT2, int WINO = 0>
+// SUMS: the per-tile channel sums (chansum / channel attention) are compiled in; callers that know there are none pass
+// false and save the 16 NB registers of the running sums (a 64-output tile has none to spare).
+template <int DT, int MB, int NB, int OUT, int RES, bool RES2, int OUT2, int WINO = 0, bool SUMS = true>
 __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f32x16 (&acc)[MB][NB],
                                          const float* lds_bias, float* lds_red) {
     constexpr bool generic = OUT == kAnyType;
@@ -148,15 +150,17 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 for (int j = 0; j < 4; ++j) { scale_r[b][q][j] = s0[j]; scale_r[b][q][4 + j] = s1[j]; }
             }
     }
-    const bool want_sums = p.chansum != nullptr || p.ca_sums != nullptr;
-    float csum[NB][2][8];
-    if (want_sums) {
+    const bool want_sums = SUMS && (p.chansum != nullptr || p.ca_sums != nullptr);
+    float csum[SUMS ? NB : 1][2][8];
+    if constexpr (SUMS) {
+        if (want_sums) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) csum[b][q][j] = 0.f;
+                    for (int j = 0; j < 8; ++j) csum[b][q][j] = 0.f;
+        }
     }
     const int ow = p.w * p.ps_r;
     const bool has_res1 = generic ? p.res1.ptr != nullptr : RES != -1;
@@ -309,13 +313,15 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 }
             }
         }
-        if (want_sums) {
+        if constexpr (SUMS) {
+            if (want_sums) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) csum[b][q][j] += inside ? v[b][q][j] : 0.f;
+                        for (int j = 0; j < 8; ++j) csum[b][q][j] += inside ? v[b][q][j] : 0.f;
+            }
         }
         if (tail && inside && k.lh == 0 && k.ct == 0) {
             float rgb[3];
@@ -335,6 +341,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
         }
     }
 
+    if constexpr (SUMS) {
     if (want_sums) {
         // deterministic tile sums: lanes -> wave (DPP adds inside each 32-lane half), waves -> LDS
         // (lds_red aliases the stage buffers, which nobody reads any more)
@@ -415,6 +422,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
                 if (k.tid == 0) __hip_atomic_store(p.ca_count + k.n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    }
     }
 }
 

@@ -508,7 +508,8 @@ __global__ __launch_bounds__(64 * kNW, 2) void rcab_fused_kernel(const ConvParam
     const EpiCtx ctx{n, 0, tile, x0, y0, wave, lx, lh, tid};
     const float* lds_bias = (const float*)(smem + G::GATE_OFF);
     float* lds_red = (float*)(smem + G::R2);
-    if (p.out.dtype == DT) epilogue<DT, 2, 2, DT, -1, false, -1>(p, ctx, acc2, lds_bias, lds_red);
+    if (p.out.dtype == DT && p.ca_sums) epilogue<DT, 2, 2, DT, -1, false, -1, 0, true>(p, ctx, acc2, lds_bias, lds_red);
+    else if (p.out.dtype == DT) epilogue<DT, 2, 2, DT, -1, false, -1, 0, false>(p, ctx, acc2, lds_bias, lds_red);
     else epilogue<DT, 2, 2, kAnyType, kAnyType, true, kAnyType>(p, ctx, acc2, lds_bias, lds_red);
 #ifdef SRMI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores and atomics of the epilogue count as its time

@@ -265,15 +265,15 @@ __global__ __launch_bounds__(64 * kNW, 2) void wino1d3x3_kernel(const ConvParams
     const int r2 = p.res2.ptr ? p.res2.dtype : -1, o2 = p.out2.ptr ? p.out2.dtype : -1;
     const bool plain_io = p.tail_mode == SRMI_TAIL_NONE && od == DT && (r2 == -1 || r2 == rd);
     if (plain_io && rd == -1 && o2 == -1) {
-        epilogue<DT, 4, 1, DT, -1, false, -1, 2>(p, ctx, o, lds_bias, lds_red);
+        epilogue<DT, 4, 1, DT, -1, false, -1, 2, false>(p, ctx, o, lds_bias, lds_red);
     } else if (plain_io && rd == SRMI_F32 && r2 == -1 && o2 == SRMI_F32) {
-        epilogue<DT, 4, 1, DT, SRMI_F32, false, SRMI_F32, 2>(p, ctx, o, lds_bias, lds_red);
+        epilogue<DT, 4, 1, DT, SRMI_F32, false, SRMI_F32, 2, false>(p, ctx, o, lds_bias, lds_red);
     } else if (plain_io && rd == SRMI_F32 && r2 == SRMI_F32 && o2 == SRMI_F32) {
-        epilogue<DT, 4, 1, DT, SRMI_F32, true, SRMI_F32, 2>(p, ctx, o, lds_bias, lds_red);
+        epilogue<DT, 4, 1, DT, SRMI_F32, true, SRMI_F32, 2, false>(p, ctx, o, lds_bias, lds_red);
     } else if (plain_io && rd == DT && r2 == -1 && o2 == -1) {
-        epilogue<DT, 4, 1, DT, DT, false, -1, 2>(p, ctx, o, lds_bias, lds_red);
+        epilogue<DT, 4, 1, DT, DT, false, -1, 2, false>(p, ctx, o, lds_bias, lds_red);
     } else if (plain_io && rd == DT && r2 == DT && o2 == DT) {
-        epilogue<DT, 4, 1, DT, DT, true, DT, 2>(p, ctx, o, lds_bias, lds_red);
+        epilogue<DT, 4, 1, DT, DT, true, DT, 2, false>(p, ctx, o, lds_bias, lds_red);
     } else {
         epilogue<DT, 4, 1, kAnyType, kAnyType, true, kAnyType, 2>(p, ctx, o, lds_bias, lds_red);
     }
