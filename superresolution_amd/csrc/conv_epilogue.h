@@ -127,16 +127,22 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
         else return k.x0 + k.lx;
     };
     const bool tail = generic && p.tail_mode != SRMI_TAIL_NONE;
+    // The lane's bias values: kept in registers for 32-output tiles; a 64-output tile (96 accumulator registers) reads
+    // them from LDS again for every row instead of holding 32 more registers through the whole epilogue.
+    constexpr bool bias_per_row = NB > 1;
     float bias_r[NB][2][8];
+    auto load_bias = [&](const int lane_half) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float* bp = lds_bias + b * 32 + 16 * q + 8 * k.lh;
-            const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+            for (int q = 0; q < 2; ++q) {
+                const float* bp = lds_bias + b * 32 + 16 * q + 8 * lane_half;
+                const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
-        }
+                for (int j = 0; j < 4; ++j) { bias_r[b][q][j] = b0[j]; bias_r[b][q][4 + j] = b1[j]; }
+            }
+    };
+    if constexpr (!bias_per_row) load_bias(k.lh);
     // int8 compute: per-output-channel dequantisation scales, laid out like the bias
     float scale_r[DT == SRMI_I8 ? NB : 1][2][8];
     if constexpr (DT == SRMI_I8) {
@@ -207,6 +213,11 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const EpiCtx& k, f
         const int y = row_y(r), x = row_x(r);
         const bool inside = (y < p.h) && (x < p.w);
         const long long pix = inside ? (long long)y * p.w + x : 0;   // dead lanes read pixel 0
+        if constexpr (bias_per_row) {
+            int lane_half = k.lh;
+            asm volatile("" : "+v"(lane_half));   // opaque per row: these reads are not merged with the other rows'
+            load_bias(lane_half);
+        }
         float v[NB][2][8];
 #pragma unroll
         for (int b = 0; b < NB; ++b)
