@@ -105,6 +105,15 @@ int srmi_rcab_prepare_device();
 // wino3x3.hip: the Winograd F(2x2,3x3) form of the convolution (srmi_conv_desc_t::algo == SRMI_ALGO_WINOGRAD)
 int srmi_wino3x3_prepare_device();
 int srmi_wino3x3_tile_rows();
+// the direct kernel's instantiations, one translation unit per compute type (conv3x3_f16.hip, ...)
+int srmi_conv3x3_launch_f16(const srmi::ConvParams& p, int mb, int nb, hipStream_t s);
+int srmi_conv3x3_launch_bf16(const srmi::ConvParams& p, int mb, int nb, hipStream_t s);
+int srmi_conv3x3_launch_f32(const srmi::ConvParams& p, int mb, int nb, hipStream_t s);
+int srmi_conv3x3_launch_i8(const srmi::ConvParams& p, int mb, int nb, hipStream_t s);
+int srmi_conv3x3_configure_f16();
+int srmi_conv3x3_configure_bf16();
+int srmi_conv3x3_configure_f32();
+int srmi_conv3x3_configure_i8();
 int srmi_wino3x3_launch(const srmi::ConvParams& p, hipStream_t stream);
 // wino1d3x3.hip: the Winograd F(2,3)-along-x form (algo == SRMI_ALGO_WINOGRAD_X)
 int srmi_wino1d3x3_prepare_device();

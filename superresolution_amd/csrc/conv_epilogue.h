@@ -1,4 +1,4 @@
-// Shared by the convolution kernels (conv3x3.hip: direct implicit GEMM; wino3x3.hip: Winograd F(2x2,3x3)): buffer
+// Shared by the convolution kernels (conv3x3_kernel.h: direct implicit GEMM; wino3x3.hip: Winograd F(2x2,3x3)): buffer
 // descriptors, the counted vmcnt wait and the fused epilogue (bias, activation, residuals, typed stores, pixel shuffle,
 // channel sums / channel attention, RGB tail).  Both kernels leave their results in the accumulator layout of
 // v_mfma_f32_32x32x16 with weights as the A operand and pixels as the B operand: a lane holds, for ONE pixel column,

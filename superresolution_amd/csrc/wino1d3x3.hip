@@ -1,5 +1,5 @@
 // 3x3 convolution with Winograd F(2,3) along x on the gfx950 matrix cores (f16 operands, f32 accumulation), same fused
-// epilogue as the direct kernel (conv3x3.hip).  Per pair of neighbouring output pixels and vertical tap, 4 multiplies
+// epilogue as the direct kernel (conv3x3_kernel.h).  Per pair of neighbouring output pixels and vertical tap, 4 multiplies
 // instead of 6: the matrix pipes do 2/3 of the direct kernel's work per algorithmic FLOP, paid for with 16 packed-f16
 // vector adds of 8 channels per 24 MFMAs.
 //

@@ -1,5 +1,5 @@
 // 3x3 convolution as Winograd F(2x2,3x3) on the gfx950 matrix cores (f16 operands, f32 accumulation), with the same
-// fused epilogue as the direct kernel (conv3x3.hip).  16 multiplies per 2x2 output tile and input channel instead of 36:
+// fused epilogue as the direct kernel (conv3x3_kernel.h).  16 multiplies per 2x2 output tile and input channel instead of 36:
 // the matrix pipes do 4/9 of the direct kernel's work per algorithmic FLOP, paid for with packed-f16 vector adds.
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A          d: 4x4 input patch of a tile, g: 3x3 filter, Y: 2x2 outputs
