@@ -115,6 +115,10 @@ int srmi_conv3x3_configure_bf16();
 int srmi_conv3x3_configure_f32();
 int srmi_conv3x3_configure_i8();
 int srmi_wino3x3_launch(const srmi::ConvParams& p, hipStream_t stream);
+// conv_rgb.hip: the RGB layer (3 outputs) as one GEMM over (tap, output) columns and a nine-tap gather
+int srmi_conv_rgb_prepare_device();
+bool srmi_conv_rgb_takes(const srmi_conv_desc_t* d);
+int srmi_conv_rgb_launch(const srmi::ConvParams& p, int cout_tile, hipStream_t stream);
 // wino1d3x3.hip: the Winograd F(2,3)-along-x form (algo == SRMI_ALGO_WINOGRAD_X)
 int srmi_wino1d3x3_prepare_device();
 void srmi_wino1d3x3_tile(int* rows, int* cols);

@@ -1,5 +1,6 @@
 // Host entry point of the direct 3x3 convolution (srmi_conv3x3): validation, tiling, dispatch to the kernel instantiations of the
-// descriptor's compute type (conv3x3_kernel.h, one translation unit per type) or to the Winograd kernels.
+// descriptor's compute type (conv3x3_kernel.h, one translation unit per type), to the Winograd kernels or, for the RGB layer,
+// to conv_rgb.hip.
 #include <stdlib.h>
 #include <string.h>
 
@@ -18,7 +19,7 @@ using namespace srmi;
 // (for instance under stream capture) consist of the launch alone.
 int srmi_conv3x3_prepare_device() {
     return (srmi_conv3x3_configure_f16() || srmi_conv3x3_configure_bf16() || srmi_conv3x3_configure_f32() || srmi_conv3x3_configure_i8() ||
-            srmi_wino3x3_prepare_device() || srmi_wino1d3x3_prepare_device()) ? -1 : 0;
+            srmi_wino3x3_prepare_device() || srmi_wino1d3x3_prepare_device() || srmi_conv_rgb_prepare_device()) ? -1 : 0;
 }
 
 extern "C" int srmi_conv3x3_tiles(int h, int w, int rows_per_wave) {
@@ -148,6 +149,9 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
         return srmi_wino1d3x3_launch(p, s);
     }
     if (wino) return srmi_wino3x3_launch(p, s);
+    // SRMI_RGB_GATHER=0 (diagnostic) keeps the RGB layer on the direct kernel
+    static const bool rgb_gather = !(getenv("SRMI_RGB_GATHER") && atoi(getenv("SRMI_RGB_GATHER")) == 0);
+    if (rgb_gather && srmi_conv_rgb_takes(d)) return srmi_conv_rgb_launch(p, d->cout_tile, s);
     const int nb = d->cout_tile / 32;
     if (d->dtype == SRMI_F16) return srmi_conv3x3_launch_f16(p, mb, nb, s);
     if (d->dtype == SRMI_BF16) return srmi_conv3x3_launch_bf16(p, mb, nb, s);

@@ -166,6 +166,31 @@ def test_rgb_tail(dt, name, tol):
         assert 0.02 < (ref8 == 0).mean() < 0.9  # clamping is exercised
 
 
+@pytest.mark.parametrize("cin,cout_tile", [(64, 64), (128, 32), (192, 32), (256, 64), (32, 32), (80, 32)])
+@pytest.mark.parametrize("dt,name", [(_lib.F16, "f16"), (_lib.BF16, "bf16")])
+def test_rgb_tail_gather_kernel_shapes(cin, cout_tile, dt, name):
+    """The RGB layer's own kernel (csrc/conv_rgb.hip: (tap, output) columns, nine-tap gather) takes 64..256 input
+    channels in steps of 64, from weights packed for either cout tile; other widths (32, 80) stay on the direct
+    kernel.  Several tiles in both directions, ragged right and bottom edges, two images."""
+    n, h, w = 2, 37, 71
+    x = q(rnd("x", (n, cin, h, w), 1), dt)
+    wt = q(rnd("w", (3, cin, 3, 3), 2, 0.05), dt)
+    b = rnd("b", (3,), 3) + 0.5
+    core = F.conv2d(x, wt, b, padding=1)
+    pc = ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=cout_tile)
+    xp = ops.Planes.from_nchw(x, dt)
+    mat = np.array([[1.0, 0.1, 0.0], [0.0, 0.9, 0.2], [0.3, 0.0, 1.1]], np.float32)
+    tb = np.array([0.5, -0.25, 0.125], np.float32)
+    ref = F.conv2d(core, torch.from_numpy(mat).view(3, 3, 1, 1), torch.from_numpy(tb))
+    got = ops.conv3x3(xp, pc, tail=dict(mode=_lib.TAIL_F32_NCHW, mat=mat, bias=tb))
+    assert_close(got.cpu(), ref, 5e-4, f"tail f32 {name} cin={cin}")
+    got = ops.conv3x3(xp, pc, tail=dict(mode=_lib.TAIL_U8_NHWC, lo=0.0, hi=1.0, scale=255.0, round=_lib.ROUND_HALF_UP))
+    ref8 = O.post_unit(core, O.ROUND_HALF_UP)
+    diff = np.abs(got.cpu().numpy().astype(np.int32) - ref8.astype(np.int32))
+    assert diff.max() <= 1, f"tail u8 {name} cin={cin}: max diff {diff.max()}"
+    assert (diff != 0).mean() < 0.1
+
+
 def test_u8_tail_matches_the_reference_python_postprocess():
     """The HIP u8 tail on exact .5 ties, near-ties and out-of-range values against the outputs of the reference's
     own postprocess / save_image functions (tests/golden/prepost_ref.npz).  An f32 convolution whose only non-zero

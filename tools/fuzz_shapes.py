@@ -5,7 +5,8 @@ output.  Then, with a third argument, that many standalone convolutions (random 
 activation, residual, dtype, image size and batch) against torch's fp32 conv2d on operands rounded to the compute
 type, an int8 convolution for every fourth of them against the exact integer convolution, and as many bilinear u8
 resizes at random sizes against the oracle (bit-exact); the f16 convolutions with input counts in multiples of 32 also in
-their two Winograd forms against the CPU emulation of those (tools/winograd_emulation.py), and every third case a
+their two Winograd forms against the CPU emulation of those (tools/winograd_emulation.py), every f16 / bf16 case also an RGB
+layer (3 outputs, 32..256 input channels, f32 and u8 results against the exact ones), and every third case a
 channel-attention block in one kernel against its two-launch form (same bits).  Every network also runs a second f16
 engine with an f16 trunk (RCAN: one-kernel blocks; RRDBNet: a Winograd form of the dense-block convolutions).
 Prints one line per failing case and a summary; exit status 1 if anything failed.
@@ -79,6 +80,21 @@ def fuzz_ops(rng, cases):
                 if gw.shape != emu.shape or e1 > 2e-5 * sc or e2 > 5e-3 * sc:
                     bad += 1
                     print(f"FAIL winograd algo={algo} cin={cin} cout={cout} n={n} h={h} w={w}: {e1:.3g} / {e2:.3g} on {sc:.3g}", flush=True)
+        if dt != _lib.F32:
+            # the RGB layer (its own kernel for 64..256 channels in steps of 64, else the direct one) against the exact result
+            cin3 = 32 * int(rng.integers(1, 9))
+            x3, w3 = rq("x3", (n, cin3, h, w)), rq("w3", (3, cin3, 3, 3), 0.05)
+            b3 = torch.from_numpy(synth.hash_uniform("b3", (3,), 1000 + i)) + 0.5
+            core = F.conv2d(x3, w3, b3, padding=1)
+            p3 = ops.PackedConv(w3.numpy(), b3.numpy(), dt, cout_tile=int(rng.choice([32, 64])))
+            X3 = ops.Planes.from_nchw(x3, dt)
+            g32 = ops.conv3x3(X3, p3, tail=dict(mode=_lib.TAIL_F32_NCHW)).cpu()
+            g8 = ops.conv3x3(X3, p3, tail=dict(mode=_lib.TAIL_U8_NHWC, lo=0.0, hi=1.0, scale=255.0, round=_lib.ROUND_HALF_UP)).cpu().numpy()
+            e3 = float((g32 - core).abs().max())
+            d8 = np.abs(g8.astype(np.int32) - O.post_unit(core, O.ROUND_HALF_UP).astype(np.int32))
+            if g32.shape != core.shape or e3 > 5e-4 * max(float(core.abs().max()), 1e-6) or d8.max() > 1:
+                bad += 1
+                print(f"FAIL rgb layer dt={dt} cin={cin3} n={n} h={h} w={w}: {e3:.3g}, u8 max diff {d8.max()}", flush=True)
         if i % 3 == 0:
             # both convolutions of a channel-attention block in one kernel against the two-launch form: same bits
             xb, yb = rq("xb", (n, 64, h, w)), rq("yb", (n, 64, h, w))
