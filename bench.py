@@ -569,7 +569,8 @@ def main():
                          "mfma_busy": pmc_record(args.model, args.dtype).get("mfma_busy"),
                          "kernel": ("rcab_fused_kernel (one launch per block, counted as its two convolutions) and "
                                     if args.model == "rcan" and args.dtype == "f16" and eng.fused_rcab() else "") +
-                                   "conv3x3_kernel<dtype,rows,cout_blocks> (all instantiations; "
+                                   "conv3x3_kernel<dtype,rows,cout_blocks> (all instantiations; the RGB layer in "
+                                   "conv_rgb_kernel, counted with its 2*Cin*3*9 FLOP per pixel; "
                                    f"{flops_frame / 1e12:.3f} algorithmic TFLOP per frame over HIP-event device time)",
                          "launches_per_frame": launches,
                          "flops_per_launch": round(flops_frame / launches),

@@ -17,9 +17,9 @@ for f in glob.glob(d + "/**/*.db", recursive=True):
     c = sqlite3.connect(f)
     for name, cname, val, dt in c.execute(
             "select kernel_name, counter_name, value, duration from counters_collection order by dispatch_id"):
-        if "conv3x3" not in name and "rcab" not in name:
+        if "conv3x3" not in name and "rcab" not in name and "conv_rgb" not in name:
             continue
-        k = name.replace("void srmi::", "").replace("(srmi::ConvParams)", "")[:60]
+        k = name.replace("void srmi::", "").replace("(anonymous namespace)::", "").replace("(srmi::ConvParams, int)", "").replace("(srmi::ConvParams)", "")[:60]
         acc[k][cname].append(float(val))
         dur[k].append(float(dt))
 print(f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
