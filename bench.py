@@ -375,6 +375,9 @@ def main():
                     help="RCAN: separate elementwise pass per channel-attention block instead of the gated conv input")
     ap.add_argument("--no-fused-rcab", action="store_true",
                     help="RCAN: the two convolutions of a block as two launches instead of one kernel")
+    ap.add_argument("--no-subpixel-up", action="store_true",
+                    help="rrdbnet: conv_up1 / conv_up2 as nine-tap convolutions reading through the x2 address map instead of "
+                         "their sub-pixel form (four 2x2 convolutions on the source grid)")
     ap.add_argument("--winograd", type=int, default=None, choices=[0, 1, 2],
                     help="RRDBNet f16: the dense blocks' convolutions in the direct form (0), the Winograd F(2x2,3x3) form (1) "
                          "or the Winograd F(2,3)-along-x form (2); default: the library's choice")
@@ -446,6 +449,8 @@ def main():
             engs[-1].set_fused_attention(False)
         if args.no_fused_rcab:
             engs[-1].set_fused_rcab(False)
+        if args.no_subpixel_up:
+            engs[-1].set_subpixel_up(False)
         if args.winograd is not None:
             engs[-1].set_winograd(args.winograd)
         engs[-1].set_lanes(args.lanes)

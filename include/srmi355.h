@@ -84,6 +84,7 @@ typedef struct {
 #define SRMI_ALGO_DIRECT 0
 #define SRMI_ALGO_WINOGRAD 1     /* F(2x2,3x3) */
 #define SRMI_ALGO_WINOGRAD_X 2   /* F(2,3) along x */
+#define SRMI_ALGO_SUBPIXEL_UP2 3 /* an in_up2 convolution as four 2x2 convolutions on the source grid */
 #define SRMI_CA_SLOTS 8   /* accumulators per image and channel of srmi_conv_desc_t::ca */
 
 /*
@@ -155,7 +156,13 @@ typedef struct {
      * input transform adds and the transformed weights are rounded to f16, so results differ from the direct form in
      * the last bits (both stay within the half-precision parity bound of the networks).
      * SRMI_ALGO_WINOGRAD_X: Winograd F(2,3) along x only (4 instead of 6 multiplies per pair of output pixels and
-     * vertical tap, weights from srmi_pack_wino1d3x3), same restrictions. */
+     * vertical tap, weights from srmi_pack_wino1d3x3), same restrictions.
+     * SRMI_ALGO_SUBPIXEL_UP2: for a convolution behind a nearest-x2 upsampling (in_up2 = 1; F.interpolate(scale_factor=2,
+     * mode='nearest') then conv, realesrgan_model.py:115-116).  Output pixel (2y + py, 2x + px) sees only 2 x 2 source pixels,
+     * each through the sum of the taps that land on it: the layer is evaluated as four 2x2 convolutions on the source grid,
+     * one per phase (py, px) — the same function with 4/9 of the multiplies.  Weights from srmi_pack_conv3x3_up2 (tap
+     * sums formed in f32, rounded once to the compute type); f16 / bf16 compute, h and w even, cout a multiple of
+     * cout_tile, rows_per_wave 2 or 3, no residuals / second output / gated input / pixel shuffle / tail / channel sums. */
     int32_t algo;
     srmi_tensor_t in_sum;
     /* Channel attention finished inside the convolution (CALayer, rcan_model.py:61-76): with ca.sums set, every
@@ -186,6 +193,14 @@ size_t srmi_pack_conv3x3_bytes(int dtype, int cout, int cin, int cout_tile, int*
  * `bias` may be NULL (zeros). Output buffers are host memory. */
 int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, int ps_r,
                       const float* w_oihw, const float* bias, void* wpk_out, float* bias_out);
+
+/* Sub-pixel form of the weights of an in_up2 convolution (srmi_conv_desc_t::algo == SRMI_ALGO_SUBPIXEL_UP2): for phase
+ * (py, px) and source tap (a, b) the sum of w[ky][kx] over the ky with (py + ky - 1) >> 1 == py - 1 + a (arithmetic shift)
+ * and the kx alike, laid out [cout tile][stage][tap 2x2][row of the tile][32 bytes] with packed output channel
+ * phase * cout + o; the bias is repeated per phase (bias_floats = 4 * cout).  cout a multiple of cout_tile. */
+size_t srmi_pack_conv3x3_up2_bytes(int dtype, int cout, int cin, int cout_tile, int* bias_floats);
+int srmi_pack_conv3x3_up2(int dtype, int cout, int cin, int cout_tile, const float* w_oihw, const float* bias,
+                          void* wpk_out, float* bias_out);
 
 /* Winograd form of the weights (srmi_conv_desc_t::algo == SRMI_ALGO_WINOGRAD, f16): U = G g G^T per (output, input)
  * channel pair, computed in double precision and rounded once to f16, laid out as the kernel stages it:
@@ -406,6 +421,13 @@ int srmi_model_set_fused_attention(srmi_model_t* m, int on);
  * vector of ones).  Both forms stay within the half-precision parity bound; see srmi_model_get_fused_rcab for the default. */
 int srmi_model_set_fused_rcab(srmi_model_t* m, int on);
 int srmi_model_get_fused_rcab(const srmi_model_t* m);
+/* RRDBNet with f16 compute: 1 (default) runs conv_up1 and conv_up2, the convolutions behind the two nearest-x2
+ * upsamplings (realesrgan_model.py:115-116), in their sub-pixel form (SRMI_ALGO_SUBPIXEL_UP2: the same function with 4/9
+ * of the multiplies; the summed taps are rounded once to the compute type, so results differ from the nine-tap form in
+ * the last bits), 0 as nine-tap convolutions that read their input through the x2 address map.  Other compute types always
+ * run the nine-tap form (srmi_conv3x3 itself offers the sub-pixel form for bf16 too). */
+int srmi_model_set_subpixel_up(srmi_model_t* m, int on);
+int srmi_model_get_subpixel_up(const srmi_model_t* m);
 /* Internal HIP streams (1..4, default 3) over which the sweeps of one forward call are spread.
  * The lanes fork from and join the caller's stream through events, so a call is ordered on the
  * caller's stream exactly as with one lane; a call with a single sweep uses the caller's stream

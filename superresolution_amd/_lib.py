@@ -32,7 +32,7 @@ class Tensor(C.Structure):
 
 
 TENSOR_ROUND8 = 1
-ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_X = 0, 1, 2
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD_X, ALGO_SUBPIXEL_UP2 = 0, 1, 2, 3
 CA_SLOTS = 8   # SRMI_CA_SLOTS
 
 
@@ -86,6 +86,7 @@ EXPORTS = [
     "srmi_conv3x3", "srmi_conv3x3_tiles", "srmi_pack_conv3x3_bytes", "srmi_pack_conv3x3",
     "srmi_pack_wino3x3_bytes", "srmi_pack_wino3x3", "srmi_pack_wino1d3x3_bytes", "srmi_pack_wino1d3x3", "srmi_model_set_winograd", "srmi_model_get_winograd",
     "srmi_rcab_fused", "srmi_model_set_fused_rcab", "srmi_model_get_fused_rcab",
+    "srmi_pack_conv3x3_up2_bytes", "srmi_pack_conv3x3_up2", "srmi_model_set_subpixel_up", "srmi_model_get_subpixel_up",
     "srmi_conv_first", "srmi_ca_scale", "srmi_ca_apply", "srmi_channel_sums",
     "srmi_pixel_shuffle", "srmi_nearest_up2", "srmi_nchw_to_planes", "srmi_planes_to_nchw",
     "srmi_resize_bilinear_u8",
@@ -126,6 +127,11 @@ def lib():
         L.srmi_pack_wino1d3x3_bytes.restype = C.c_size_t
         L.srmi_pack_wino1d3x3_bytes.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.srmi_pack_wino1d3x3.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.srmi_pack_conv3x3_up2_bytes.restype = C.c_size_t
+        L.srmi_pack_conv3x3_up2_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.srmi_pack_conv3x3_up2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.srmi_model_set_subpixel_up.argtypes = [C.c_void_p, C.c_int]
+        L.srmi_model_get_subpixel_up.argtypes = [C.c_void_p]
         L.srmi_model_set_winograd.argtypes = [C.c_void_p, C.c_int]
         L.srmi_model_get_winograd.argtypes = [C.c_void_p]
         L.srmi_rcab_fused.argtypes = [C.POINTER(RcabDesc), C.c_void_p]

@@ -114,6 +114,11 @@ int srmi_conv3x3_configure_f16();
 int srmi_conv3x3_configure_bf16();
 int srmi_conv3x3_configure_f32();
 int srmi_conv3x3_configure_i8();
+// the sub-pixel form of an upsampling convolution (algo == SRMI_ALGO_SUBPIXEL_UP2; conv3x3_up2_{f16,bf16}.hip)
+int srmi_conv3x3_launch_up2_f16(const srmi::ConvParams& p, int mb, int nb, hipStream_t s);
+int srmi_conv3x3_launch_up2_bf16(const srmi::ConvParams& p, int mb, int nb, hipStream_t s);
+int srmi_conv3x3_configure_up2_f16();
+int srmi_conv3x3_configure_up2_bf16();
 int srmi_wino3x3_launch(const srmi::ConvParams& p, hipStream_t stream);
 // conv_rgb.hip: the RGB layer (3 outputs) as one GEMM over (tap, output) columns and a nine-tap gather
 int srmi_conv_rgb_prepare_device();

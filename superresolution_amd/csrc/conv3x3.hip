@@ -19,6 +19,7 @@ using namespace srmi;
 // (for instance under stream capture) consist of the launch alone.
 int srmi_conv3x3_prepare_device() {
     return (srmi_conv3x3_configure_f16() || srmi_conv3x3_configure_bf16() || srmi_conv3x3_configure_f32() || srmi_conv3x3_configure_i8() ||
+            srmi_conv3x3_configure_up2_f16() || srmi_conv3x3_configure_up2_bf16() ||
             srmi_wino3x3_prepare_device() || srmi_wino1d3x3_prepare_device() || srmi_conv_rgb_prepare_device()) ? -1 : 0;
 }
 
@@ -47,7 +48,17 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     if (d->cout_tile != 32 && d->cout_tile != 64) SRMI_FAIL("srmi_conv3x3: cout_tile must be 32 or 64");
     const bool wino_x = d->algo == SRMI_ALGO_WINOGRAD_X;
     const bool wino = d->algo == SRMI_ALGO_WINOGRAD || wino_x;
-    if (d->algo != SRMI_ALGO_DIRECT && !wino) SRMI_FAIL("srmi_conv3x3: unknown algo %d", d->algo);
+    const bool subpix = d->algo == SRMI_ALGO_SUBPIXEL_UP2;
+    if (d->algo != SRMI_ALGO_DIRECT && !wino && !subpix) SRMI_FAIL("srmi_conv3x3: unknown algo %d", d->algo);
+    if (subpix) {
+        if (d->dtype != SRMI_F16 && d->dtype != SRMI_BF16) SRMI_FAIL("srmi_conv3x3: the sub-pixel form computes in f16 or bf16");
+        if (!d->in_up2) SRMI_FAIL("srmi_conv3x3: the sub-pixel form is the form of an in_up2 convolution");
+        if (d->ps_r > 1 || d->res1.ptr || d->res2.ptr || d->out2.ptr || d->in_gate.ptr || d->tail_mode != SRMI_TAIL_NONE ||
+            d->ca.sums || d->chansum || !d->out.ptr)
+            SRMI_FAIL("srmi_conv3x3: the sub-pixel form writes one plane tensor and excludes residuals, a second output, gated "
+                      "input, pixel shuffle, tail, channel sums and channel attention");
+        if (d->cout <= 0 || d->cout % d->cout_tile) SRMI_FAIL("srmi_conv3x3: cout=%d is not a multiple of cout_tile=%d", d->cout, d->cout_tile);
+    }
     if (wino) {
         if (d->dtype != SRMI_F16) SRMI_FAIL("srmi_conv3x3: the Winograd form computes in f16 only");
         if (d->cin % 32) SRMI_FAIL("srmi_conv3x3: the Winograd form needs cin to be a multiple of 32 (got %d)", d->cin);
@@ -58,6 +69,7 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
     // the Winograd kernel has one tile shape: 16 rows (4 per wave)
     const int mb = wino_x ? 2 : wino ? srmi_wino3x3_tile_rows() / kNW : (d->rows_per_wave ? d->rows_per_wave : default_rows_per_wave());
     if (mb < 2 || mb > 4) SRMI_FAIL("srmi_conv3x3: rows_per_wave must be 2, 3 or 4");
+    if (subpix && mb == 4) SRMI_FAIL("srmi_conv3x3: the sub-pixel form needs rows_per_wave 2 or 3");
     if (d->cout_tile == 64 && mb == 4) SRMI_FAIL("srmi_conv3x3: rows_per_wave 4 needs cout_tile 32");
     const bool tail = d->tail_mode != SRMI_TAIL_NONE;
     if (tail) {
@@ -149,6 +161,17 @@ extern "C" int srmi_conv3x3(const srmi_conv_desc_t* d, void* hip_stream) {
         return srmi_wino1d3x3_launch(p, s);
     }
     if (wino) return srmi_wino3x3_launch(p, s);
+    if (subpix) {
+        // the kernel runs on the source grid: four phases of cout outputs each, stored through the pixel-shuffle map
+        p.h = d->h / 2; p.w = d->w / 2;
+        p.in_up2 = 0;
+        p.cout = p.cout_real = 4 * d->cout;
+        p.ps_r = 2; p.ps_c = d->cout;
+        p.tiles_x = (p.w + kTileW - 1) / kTileW;
+        p.tiles_y = (p.h + kNW * mb - 1) / (kNW * mb);
+        const int nb2 = d->cout_tile / 32;
+        return d->dtype == SRMI_F16 ? srmi_conv3x3_launch_up2_f16(p, mb, nb2, s) : srmi_conv3x3_launch_up2_bf16(p, mb, nb2, s);
+    }
     // SRMI_RGB_GATHER=0 (diagnostic) keeps the RGB layer on the direct kernel
     static const bool rgb_gather = !(getenv("SRMI_RGB_GATHER") && atoi(getenv("SRMI_RGB_GATHER")) == 0);
     if (rgb_gather && srmi_conv_rgb_takes(d)) return srmi_conv_rgb_launch(p, d->cout_tile, s);

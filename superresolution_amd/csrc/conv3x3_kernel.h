@@ -83,13 +83,15 @@ __device__ __forceinline__ void mma_chunk(f32x16& c, const u32x4& wfrag, const u
 }
 
 
-template <int MB, int NB>
+// KT: taps per direction.  3: the 3x3 convolution.  2: one phase of a 3x3 convolution behind a nearest-x2 upsampling, which
+// on the source grid is a 2x2 convolution (below).
+template <int MB, int NB, int KT = 3>
 struct ConvGeom {
-    static constexpr int TH = kNW * MB, PH = TH + 2, PW = kPatchW;
+    static constexpr int TH = kNW * MB, PH = TH + KT - 1, PW = kPatchW;
     static constexpr int NCH = PH * PW * 2;                // 16-byte chunks of one pixel-patch stage
     static constexpr int A_PIECES = (NCH + 63) / 64;       // 1-KiB LDS-DMA pieces
     static constexpr int A_BYTES = A_PIECES * 1024;
-    static constexpr int B_BYTES = 9 * 32 * NB * 32;       // weight image of one stage
+    static constexpr int B_BYTES = KT * KT * 32 * NB * 32;  // weight image of one stage
     static constexpr int B_PIECES = B_BYTES / 1024;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     // ring of stages: three deep (two stages in flight behind the one being multiplied) where two
@@ -111,10 +113,17 @@ struct ConvGeom {
 
 // CARRIED: the main loop's form (below), chosen by the host from the number of stages: one kernel holds one form, so the
 // accumulators of the two loops never meet in copies (or spills) in front of the epilogue.
-template <int DT, int MB, int NB, int GATE, bool CARRIED = false>
-__global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
+//
+// KT == 2, the sub-pixel form of "nearest-x2 upsampling, then 3x3 convolution": output pixel (2y + py, 2x + px) only sees
+// the source pixels (y + py - 1 .. y + py, x + px - 1 .. x + px), each through the sum of the taps that land on it, so
+// the layer is four 2x2 convolutions on the SOURCE grid (4/9 of the multiplies), one per phase (py, px).  The host packs
+// the summed weights phase-major (srmi_pack_conv3x3_up2); a workgroup's output-channel tile lies inside one phase, which
+// shifts its patch origin, and the results leave through the pixel-shuffle store (ps_r == 2).
+template <int DT, int MB, int NB, int GATE, bool CARRIED = false, int KT = 3>
+__global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB, KT>::MIN_WAVES)) void conv3x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
-    using G = ConvGeom<MB, NB>;
+    static_assert(KT == 3 || (KT == 2 && !GATE && !CARRIED), "the 2x2 form: plain input, classic loop");
+    using G = ConvGeom<MB, NB, KT>;
     constexpr int TH = G::TH, PW = G::PW;
     constexpr int APW = (G::A_PIECES + kNW - 1) / kNW, BPW = (G::B_PIECES + kNW - 1) / kNW;  // pieces per wave
 
@@ -151,6 +160,9 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
     // LDS chunk i holds logical chunk c = (i&1) ^ ((pixel>>3)&1) of patch pixel i>>1.
     unsigned aoff[APW];
     {
+        // 2x2 form: the phase of this output-channel tile moves the patch origin from (y0 - 1, x0 - 1) to (y0 - 1 + py, x0 - 1 + px)
+        const int phase = KT == 2 ? (ct * 32 * NB) / p.ps_c : 0;
+        const int sy = phase >> 1, sx = phase & 1;
         const int srcW = p.in_up2 ? (p.w >> 1) : p.w;
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
             const int pp = i >> 1;
             const int c = (i & 1) ^ ((pp >> 3) & 1);
             const int rho = pp / PW, xi = pp - rho * PW;
-            int gy = y0 - 1 + rho, gx = x0 - 1 + xi;
+            int gy = y0 - 1 + rho + sy, gx = x0 - 1 + xi + sx;
             const bool ok = (i < G::NCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
             if (p.in_up2) { gy >>= 1; gx >>= 1; }
             aoff[j] = ok ? ((unsigned)(gy * srcW + gx) * 32u + (unsigned)c * 16u) : SRMI_OOB_OFFSET;
@@ -419,19 +431,19 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
     // One fragment set = everything the MFMAs of one horizontal tap (dx) read from LDS.  Two sets
     // are alternated so that the ds_reads of step i+1 are in flight while step i multiplies.
     struct Frag {
-        u32x4 wf[3][NB];
-        u32x4 pf[MB + 2];
+        u32x4 wf[KT][NB];
+        u32x4 pf[MB + KT - 1];
     };
     auto load_frag = [&](Frag& f, const char* Ab, const char* Bb, const int dx) {
 #ifdef SRMI_ABL_NO_LDS  // timing ablation (wrong results): fragments are read once and reused
         if (dx != 0 || Ab != smem) return;
 #endif
 #pragma unroll
-        for (int rho = 0; rho < MB + 2; ++rho) {
-            if (rho < 3) {
+        for (int rho = 0; rho < MB + KT - 1; ++rho) {
+            if (rho < KT) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    f.wf[rho][b] = *(const u32x4*)(Bb + ((rho * 3 + dx) * 32 * NB + b * 32) * 32 + ((lh ^ bm) << 4));
+                    f.wf[rho][b] = *(const u32x4*)(Bb + ((rho * KT + dx) * 32 * NB + b * 32) * 32 + ((lh ^ bm) << 4));
             }
             const int pp = p0 + rho * PW + dx;
 #ifdef SRMI_ABL_DX_COPY  // timing ablation (wrong results): only the first horizontal tap reads pixel fragments
@@ -446,10 +458,10 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
     int mfma_i = 0;
     auto mma_frag = [&](const Frag& f, const int part, auto&& after) {
 #pragma unroll
-        for (int rho = 0; rho < MB + 2; ++rho) {
+        for (int rho = 0; rho < MB + KT - 1; ++rho) {
             if ((rho == 0) != (part == 0)) continue;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
+            for (int dy = 0; dy < KT; ++dy) {
                 const int r = rho - dy;
                 if (r >= 0 && r < MB) {
 #pragma unroll
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
 #ifdef SRMI_GAP_OVERRIDE  // diagnostic build: issue the next stage's pieces closer together, earlier in the stage
     constexpr int GAP = SRMI_GAP_OVERRIDE;
 #else
-    constexpr int GAP = (9 * MB * NB) / PPW;  // multiply steps between two DMA pieces
+    constexpr int GAP = (KT * KT * MB * NB) / PPW;  // multiply steps between two DMA pieces
 #endif
     static_assert(GAP >= 1, "a stage needs at least as many multiply steps as DMA pieces per wave");
 
@@ -614,6 +626,21 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
         // (nothing else is outstanding yet); then the next set's ds_reads are issued and run
         // under the remaining MFMAs, so the following step's wait finds them complete.
         mfma_i = 0;
+        if constexpr (KT == 2) {
+            // two horizontal taps: both fragment sets are requested up front, the second lands under the first's MFMAs
+            Frag f0, f1;
+            load_frag(f0, Ab, Bb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f0, 0, after);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(f1, Ab, Bb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f0, 1, after);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_frag(f1, 0, after);
+            mma_frag(f1, 1, after);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #ifdef SRMI_SINGLE_FRAG  // diagnostic build: one fragment set, reloaded per horizontal tap (fewer registers)
         Frag f0;
 #pragma unroll
@@ -648,6 +675,7 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
         mma_frag(f0, 1, after);
         __builtin_amdgcn_sched_barrier(0);
 #endif
+        }
         STAMP();
         cur = cur + 1 == G::NS ? 0 : cur + 1;
     }
@@ -727,41 +755,54 @@ __global__ __launch_bounds__(64 * kNW, (GATE ? 2 : ConvGeom<MB, NB>::MIN_WAVES))
 // The dynamic-LDS limit is a per-device attribute of the function: set once on every device used.  Setting
 // it twice is harmless, so concurrent first calls only need the bookkeeping itself to be atomic.
 // (a plain input on the two-slot ring has both loop forms: two kernels)
-template <int MB, int NB, int GATE>
-constexpr bool kHasCarried = !GATE && ConvGeom<MB, NB>::NS == 2;
+template <int MB, int NB, int GATE, int KT = 3>
+constexpr bool kHasCarried = !GATE && KT == 3 && ConvGeom<MB, NB, KT>::NS == 2;
 constexpr int kCarriedMinStages = 8;   // stages from which the fragment-carried loop is the faster one
 
-template <int DT, int MB, int NB, int GATE>
+template <int DT, int MB, int NB, int GATE, int KT = 3>
 static int configure() {
     static std::atomic<unsigned long long> configured{0};
     int dev = 0;
     SRMI_HIP(hipGetDevice(&dev));
     const bool tracked = dev >= 0 && dev < 64;
     if (!tracked || !(configured.load(std::memory_order_acquire) >> dev & 1ull)) {
-        constexpr int lds = (int)ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0);
-        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB, GATE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        if constexpr (kHasCarried<MB, NB, GATE>)
+        constexpr int lds = (int)ConvGeom<MB, NB, KT>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB, KT>::GATE_BYTES : 0);
+        SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB, GATE, false, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (kHasCarried<MB, NB, GATE, KT>)
             SRMI_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<DT, MB, NB, GATE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if (tracked) configured.fetch_or(1ull << dev, std::memory_order_release);
     }
     return 0;
 }
 
-template <int DT, int MB, int NB, int GATE = 0>
+template <int DT, int MB, int NB, int GATE = 0, int KT = 3>
 static int launch(const ConvParams& p, hipStream_t stream) {
-    constexpr size_t lds = ConvGeom<MB, NB>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB>::GATE_BYTES : 0);
-    if (configure<DT, MB, NB, GATE>()) return -1;
+    constexpr size_t lds = ConvGeom<MB, NB, KT>::LDS_TOTAL + (GATE ? ConvGeom<MB, NB, KT>::GATE_BYTES : 0);
+    if (configure<DT, MB, NB, GATE, KT>()) return -1;
     dim3 grid(p.tiles_x * p.tiles_y, p.cout / (32 * NB), p.n);
-    if constexpr (kHasCarried<MB, NB, GATE>) {
+    if constexpr (kHasCarried<MB, NB, GATE, KT>) {
         if (p.ncb >= kCarriedMinStages) {
             hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB, GATE, true>), grid, dim3(64 * kNW), lds, stream, p);
             SRMI_HIP(hipGetLastError());
             return 0;
         }
     }
-    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB, GATE, false>), grid, dim3(64 * kNW), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<DT, MB, NB, GATE, false, KT>), grid, dim3(64 * kNW), lds, stream, p);
     SRMI_HIP(hipGetLastError());
     return 0;
+}
+
+// the 2x2 (sub-pixel) form: 8- and 12-row tiles, 32 or 64 outputs per workgroup
+template <int DT>
+static int launch_up2_dt(const ConvParams& p, int mb, int nb, hipStream_t s) {
+    if (mb != 2 && mb != 3) SRMI_FAIL("srmi_conv3x3: the sub-pixel form needs rows_per_wave 2 or 3");
+    if (nb == 1) return mb == 2 ? launch<DT, 2, 1, 0, 2>(p, s) : launch<DT, 3, 1, 0, 2>(p, s);
+    return mb == 2 ? launch<DT, 2, 2, 0, 2>(p, s) : launch<DT, 3, 2, 0, 2>(p, s);
+}
+
+template <int DT>
+static int configure_up2_dt() {
+    return configure<DT, 2, 1, 0, 2>() || configure<DT, 3, 1, 0, 2>() || configure<DT, 2, 2, 0, 2>() || configure<DT, 3, 2, 0, 2>();
 }
 
 template <int DT>

@@ -25,7 +25,7 @@ constexpr int kRows = 16;                          // output rows of a tile (32 
 constexpr int kPH = kRows + 2, kPW = kPatchW;      // the patch: one pixel of halo on every side
 constexpr int kPatch = kPH * kPW;                  // 612 pixels
 constexpr int kBlocks = (kPatch + 31) / 32;        // MFMA column blocks of 32 patch pixels
-constexpr int kBPW = kBlocks / kNW;                // blocks per wave
+[[maybe_unused]] constexpr int kBPW = kBlocks / kNW;  // blocks per wave (used in device code)
 constexpr int kPPad = kBlocks * 32;
 constexpr int kCols = 27;                          // (tap, output) pairs
 constexpr int kLdsBytes = kCols * kPPad * 4;       // Y[column][patch pixel], f32

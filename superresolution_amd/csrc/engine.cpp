@@ -49,6 +49,9 @@ struct HostTensor {
 struct ConvW {
     void* wpk_wino = nullptr;  // Winograd F(2x2,3x3) form of the same weights (RRDBNet dense blocks, f16), else null
     void* wpk_wino_x = nullptr;  // Winograd F(2,3)-along-x form
+    void* wpk_up2 = nullptr;     // sub-pixel form (four 2x2 convolutions on the source grid) of a convolution behind a
+    float* bias_up2 = nullptr;   // nearest-x2 upsampling (RRDBNet conv_up1 / conv_up2, f16), else null
+    int cout_tile_up2 = 32;
     void* wpk = nullptr;
     float* bias = nullptr;
     float* wscale = nullptr;  // int8 convs: per-output-channel dequantisation scale
@@ -94,6 +97,7 @@ struct srmi_model {
     size_t ws_bytes = 0;
     int sweep = 1;
     bool fuse_attention = true;  // RCAN, half-precision trunk: attention output formed by the consuming conv
+    bool subpixel_up = true;     // RRDBNet, f16: conv_up1 / conv_up2 in their sub-pixel form (4/9 of the multiplies)
     bool fuse_rcab = true;       // RCAN / EDSR, f16 operands, 64 features: both convolutions of a block in one kernel (srmi_rcab_fused)
     int mb_override = 0;
     // RRDBNet, f16: the grown channels x1..x4 of every dense block (and the weights that multiply them)
@@ -311,6 +315,23 @@ static int upload_conv(srmi_model* m, const std::string& name, int ps_r) {
             if (dev_upload(m, up.data(), xb, &cw.wpk_wino_x)) return -1;
         }
     }
+    // the convolutions behind RRDBNet's nearest-x2 upsamplings also in their sub-pixel form (from the unrounded weights:
+    // the tap sums are rounded once)
+    // (f16 only: with bf16's 8-bit significands the extra rounding of the sums costs the network 1 dB)
+    if (m->d.arch == SRMI_ARCH_RRDBNET && m->cdt() == SRMI_F16 &&
+        (name == "conv_up1" || name == "conv_up2") && cw.cout % cw.cout_tile == 0) {
+        int nb2 = 0;
+        // one phase of 64 outputs per workgroup where the width allows (measured: 183 against 207 us for conv_up2 at 2040x1356)
+        cw.cout_tile_up2 = cw.cout % 64 == 0 ? 64 : cw.cout_tile;
+        const size_t ub = srmi_pack_conv3x3_up2_bytes(m->cdt(), cw.cout, cw.cin, cw.cout_tile_up2, &nb2);
+        if (ub) {
+            std::vector<char> up(ub);
+            std::vector<float> b2(nb2);
+            if (srmi_pack_conv3x3_up2(m->cdt(), cw.cout, cw.cin, cw.cout_tile_up2, w.data.data(), b.data.data(), up.data(), b2.data())) return -1;
+            if (dev_upload(m, up.data(), ub, &cw.wpk_up2)) return -1;
+            if (dev_upload(m, b2.data(), nb2 * sizeof(float), (void**)&cw.bias_up2)) return -1;
+        }
+    }
     m->convs[name] = cw;
     return 0;
 }
@@ -423,6 +444,14 @@ struct Exec {
             d.algo = m->winograd;
             d.wpk = wino_w;
             d.rows_per_wave = 0;
+        }
+        // an upsampling convolution in its sub-pixel form (not while calibrating, as above)
+        if (up2 && cw.wpk_up2 && m->subpixel_up && !res1 && !res2 && !out2 && !gate && !att && !chansum && !m->calibrating &&
+            d.rows_per_wave <= 3) {
+            d.algo = SRMI_ALGO_SUBPIXEL_UP2;
+            d.wpk = cw.wpk_up2;
+            d.bias = cw.bias_up2;
+            d.cout_tile = cw.cout_tile_up2;
         }
         d.alpha = alpha; d.beta = beta;
         if (res1) d.res1 = *res1;
@@ -1568,6 +1597,15 @@ extern "C" int srmi_model_set_fused_rcab(srmi_model_t* m, int on) {
 }
 
 extern "C" int srmi_model_get_fused_rcab(const srmi_model_t* m) { return (m && m->fuse_rcab) ? 1 : 0; }
+
+extern "C" int srmi_model_set_subpixel_up(srmi_model_t* m, int on) {
+    if (!m) SRMI_FAIL("srmi_model_set_subpixel_up: null model");
+    std::lock_guard<std::mutex> lock(m->call_mutex);
+    m->subpixel_up = on != 0;
+    return 0;
+}
+
+extern "C" int srmi_model_get_subpixel_up(const srmi_model_t* m) { return (m && m->subpixel_up) ? 1 : 0; }
 
 extern "C" int srmi_model_set_sweep(srmi_model_t* m, int images_per_sweep) {
     if (!m || images_per_sweep < 1) SRMI_FAIL("srmi_model_set_sweep: bad argument");

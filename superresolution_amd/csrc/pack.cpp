@@ -118,6 +118,52 @@ extern "C" int srmi_pack_conv3x3(int dtype, int cout, int cin, int cout_tile, in
     return 0;
 }
 
+// Sub-pixel form of "nearest-x2 upsampling, then 3x3 convolution": row Y = 2y + py of the upsampled image reads source rows
+// (Y + ky - 1) >> 1 = y - 1 + py + a with a in {0, 1}; taps that land on the same source row are added (f32), and
+// likewise along x.  Packed output channel q = phase * cout + o, phase = 2 py + px (what the pixel-shuffle store expects).
+extern "C" size_t srmi_pack_conv3x3_up2_bytes(int dtype, int cout, int cin, int cout_tile, int* bias_floats) {
+    if (dtype != SRMI_F16 && dtype != SRMI_BF16) return 0;
+    if (cin <= 0 || cin % 16 || cout <= 0 || (cout_tile != 32 && cout_tile != 64) || cout % cout_tile) return 0;
+    if (bias_floats) *bias_floats = 4 * cout;
+    return (size_t)(4 * cout / cout_tile) * (cin / 16) * 4 * cout_tile * 32;
+}
+
+extern "C" int srmi_pack_conv3x3_up2(int dtype, int cout, int cin, int cout_tile, const float* w, const float* bias,
+                                     void* wpk_out, float* bias_out) {
+    int nbias = 0;
+    const size_t bytes = srmi_pack_conv3x3_up2_bytes(dtype, cout, cin, cout_tile, &nbias);
+    if (!bytes) SRMI_FAIL("srmi_pack_conv3x3_up2: bad shape dtype=%d cout=%d cin=%d cout_tile=%d", dtype, cout, cin, cout_tile);
+    if (!w || !wpk_out || !bias_out) SRMI_FAIL("srmi_pack_conv3x3_up2: null pointer");
+    const int nstage = cin / 16, ntile = nbias / cout_tile;
+    char* out = (char*)wpk_out;
+    for (int t = 0; t < ntile; ++t)
+        for (int st = 0; st < nstage; ++st)
+            for (int tap = 0; tap < 4; ++tap)
+                for (int row = 0; row < cout_tile; ++row) {
+                    const int q = t * cout_tile + row, phase = q / cout, o = q - phase * cout;
+                    const int py = phase >> 1, px = phase & 1, a = tap >> 1, b = tap & 1;
+                    const int img_row = tap * cout_tile + row;
+                    char* dst_row = out + ((((size_t)t * nstage + st) * 4 + tap) * cout_tile + row) * 32;
+                    for (int c = 0; c < 2; ++c) {
+                        char* dst = dst_row + ((c ^ ((img_row >> 3) & 1)) << 4);
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = st * 16 + c * 8 + e;
+                            float v = 0.f;
+                            for (int ky = 0; ky < 3; ++ky)
+                                for (int kx = 0; kx < 3; ++kx) {
+                                    // floor((p + k - 1) / 2) for p in {0, 1}: -1, 0, 0 (p = 0) and 0, 0, 1 (p = 1)
+                                    const int ry = (py + ky + 1) / 2 - 1, rx = (px + kx + 1) / 2 - 1;
+                                    if (ry == py - 1 + a && rx == px - 1 + b) v += w[((size_t)o * cin + ci) * 9 + ky * 3 + kx];
+                                }
+                            const uint16_t hv = dtype == SRMI_F16 ? f32_to_f16(v) : f32_to_bf16(v);
+                            memcpy(dst + 2 * e, &hv, 2);
+                        }
+                    }
+                }
+    for (int q = 0; q < nbias; ++q) bias_out[q] = bias ? bias[q % cout] : 0.f;
+    return 0;
+}
+
 // Winograd F(2x2,3x3): U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], per (output, input) channel pair.
 extern "C" size_t srmi_pack_wino3x3_bytes(int cout, int cin, int* bias_floats) {
     if (cin <= 0 || cin % 16 || cout <= 0) return 0;

@@ -91,6 +91,14 @@ class Engine:
     def fused_rcab(self):
         return bool(lib().srmi_model_get_fused_rcab(self._h))
 
+    def set_subpixel_up(self, on=True):
+        """RRDBNet, f16 compute: conv_up1 / conv_up2 (behind the nearest-x2 upsamplings) as four 2x2 convolutions on
+        the source grid (True: 4/9 of the multiplies) or as nine-tap convolutions reading through the x2 address map."""
+        check(lib().srmi_model_set_subpixel_up(self._h, int(bool(on))), "srmi_model_set_subpixel_up")
+
+    def subpixel_up(self):
+        return bool(lib().srmi_model_get_subpixel_up(self._h))
+
     def set_winograd(self, on=True):
         """RRDBNet, f16 compute: run the dense blocks' convolutions in the direct form (False / 0), the Winograd
         F(2x2,3x3) form (True / 1) or the Winograd F(2,3)-along-x form (2); takes effect at the next forward."""

@@ -74,10 +74,12 @@ _NULL = Tensor()
 class PackedConv:
     """Weights of one 3x3 convolution in the kernel's device format."""
 
-    def __init__(self, weight, bias, dtype, cout_tile=None, ps_r=1, device="cuda", wscale=None, winograd=False):
+    def __init__(self, weight, bias, dtype, cout_tile=None, ps_r=1, device="cuda", wscale=None, winograd=False,
+                 subpixel_up2=False):
         """dtype I8: `weight` holds integer values in [-127, 127] and `wscale` the per-output-channel factor the
         int32 accumulator is multiplied with (weight scale * input activation scale).
-        winograd: pack for the Winograd F(2x2,3x3) form of the convolution (f16, cout_tile 32)."""
+        winograd: pack for the Winograd F(2x2,3x3) form of the convolution (f16, cout_tile 32).
+        subpixel_up2: pack the sub-pixel form of a convolution that is used with up2=True (f16 / bf16)."""
         w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))
         cout, cin = w.shape[:2]
         assert w.shape[2:] == (3, 3)
@@ -85,10 +87,14 @@ class PackedConv:
             cout_tile = 32 if (cout <= 32 or winograd) else 64
         self.cout, self.cin, self.dtype, self.cout_tile, self.ps_r = cout, cin, dtype, cout_tile, ps_r
         # winograd: False / 0 (direct), True / 1 (F(2x2,3x3)), 2 (F(2,3) along x)
-        self.algo = int(winograd)
+        self.algo = _lib.ALGO_SUBPIXEL_UP2 if subpixel_up2 else int(winograd)
         nb = C.c_int(0)
         b = None if bias is None else np.ascontiguousarray(np.asarray(bias, dtype=np.float32))
-        if winograd:
+        if subpixel_up2:
+            if winograd or ps_r != 1:
+                raise _lib.SrmiError("the sub-pixel form excludes the Winograd forms and the pixel-shuffle store")
+            nbytes = lib().srmi_pack_conv3x3_up2_bytes(dtype, cout, cin, cout_tile, C.byref(nb))
+        elif winograd:
             if dtype != F16 or cout_tile != 32 or ps_r != 1:
                 raise _lib.SrmiError("the Winograd form needs f16, cout_tile 32 and no pixel shuffle")
             nbytes = (lib().srmi_pack_wino1d3x3_bytes if self.algo == _lib.ALGO_WINOGRAD_X else
@@ -99,7 +105,10 @@ class PackedConv:
             raise _lib.SrmiError(f"cannot pack conv weight {w.shape} for dtype {dtype}")
         wp = np.empty(nbytes, dtype=np.uint8)
         bp = np.empty(nb.value, dtype=np.float32)
-        if winograd:
+        if subpixel_up2:
+            check(lib().srmi_pack_conv3x3_up2(dtype, cout, cin, cout_tile, w.ctypes.data, None if b is None else b.ctypes.data,
+                                              wp.ctypes.data, bp.ctypes.data), "pack_conv3x3_up2")
+        elif winograd:
             pack = lib().srmi_pack_wino1d3x3 if self.algo == _lib.ALGO_WINOGRAD_X else lib().srmi_pack_wino3x3
             check(pack(cout, cin, w.ctypes.data, None if b is None else b.ctypes.data, wp.ctypes.data, bp.ctypes.data),
                   "pack_wino3x3")

@@ -81,6 +81,36 @@ def test_f16_without_f32_trunk_is_reported():
     assert diff.max() <= 1 and O.psnr_u8(got, ref) >= 50.0
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("scale", [4, 2])
+def test_rrdbnet_upsampling_convs_in_both_forms(dtype, scale):
+    """conv_up1 / conv_up2 (behind the nearest-x2 upsamplings, realesrgan_model.py:115-116) run as four 2x2 convolutions
+    on the source grid by default and as nine-tap convolutions with set_subpixel_up(False): the two results lie next to
+    each other (the summed taps are rounded once more) and within the half-precision bound of the oracle.  The engine
+    uses the sub-pixel form with f16 compute only: with bf16 the switch changes nothing."""
+    meta = dict(arch="rrdbnet", num_block=2, scale=scale, seed=31, input="unit")
+    model, sd = H.build_model(meta, dtype, trunk_f32=False)
+    eng = model.engine()
+    assert eng.subpixel_up()
+    imgs = np.stack([synth.smooth_image(37, 53, 5), synth.random_image(37, 53, 6)])
+    with torch.no_grad():
+        ref = O.post_unit(H.oracle_forward(meta, sd, O.pre_unit(imgs)), O.ROUND_HALF_UP)
+    outs = {}
+    for on in (True, False):
+        eng.set_subpixel_up(on)
+        outs[on] = model.forward_u8(imgs, _lib.ROUND_HALF_UP).numpy()
+        d = np.abs(outs[on].astype(np.int32) - ref.astype(np.int32))
+        print(f"rrdbnet x{scale} {dtype} sub-pixel upsampling convs={on}: max u8 diff {d.max()}, PSNR {O.psnr_u8(outs[on], ref):.2f} dB")
+        if dtype == "f16":
+            assert d.max() <= 1 and O.psnr_u8(outs[on], ref) >= 50.0
+    eng.set_subpixel_up(True)
+    d12 = np.abs(outs[True].astype(np.int32) - outs[False].astype(np.int32))
+    if dtype == "bf16":
+        assert d12.max() == 0
+    else:
+        assert d12.max() <= 1 and (d12 != 0).mean() < 0.05 and (d12 != 0).any(), (d12.max(), (d12 != 0).mean())
+
+
 @pytest.mark.parametrize("trunk_f32", [True, False])
 def test_bench_configuration_full_size_frame(trunk_f32):
     """The benchmark's exact workload (RealESRGAN_x4plus, 23 blocks, 510x339 -> 2040x1356, f16)

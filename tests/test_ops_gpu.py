@@ -126,6 +126,44 @@ def test_nearest_up2_loader(dt, name, tol):
     assert_close(out.to_nchw().cpu(), ref, tol, f"up2 {name}")
 
 
+@pytest.mark.parametrize("dt,name,tol", [(_lib.F16, "f16", 2.0 ** -10), (_lib.BF16, "bf16", 2.0 ** -7)])
+@pytest.mark.parametrize("cin,cout,cout_tile,mb", [(64, 64, 32, 3), (64, 64, 64, 2), (96, 32, 32, 2), (32, 128, 64, 3)])
+def test_upsampling_conv_subpixel_form(dt, name, tol, cin, cout, cout_tile, mb):
+    """nearest-x2 upsampling, then conv (realesrgan_model.py:115-116) as four 2x2 convolutions on the source grid
+    (SRMI_ALGO_SUBPIXEL_UP2): against torch on the upsampled tensor, and against the nine-tap kernel reading through the
+    x2 address map.  The tap sums are rounded once to the compute type, so the forms agree to a rounding of the weights,
+    not bit for bit.  Several tiles both ways, ragged edges, two images."""
+    n, h, w = 2, 27, 41
+    x = q(rnd("x", (n, cin, h, w), 1), dt)
+    wt = q(rnd("w", (cout, cin, 3, 3), 2, 0.1), dt)
+    b = rnd("b", (cout,), 3)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1), 0.2)
+    xp = ops.Planes.from_nchw(x, dt)
+    sub = ops.conv3x3(xp, ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=cout_tile, subpixel_up2=True),
+                      act=_lib.ACT_LRELU, up2=True, rows_per_wave=mb)
+    assert (sub.c, sub.h, sub.w) == (cout, 2 * h, 2 * w)
+    # one more rounding (of the summed taps) than the nine-tap form
+    assert_close(sub.to_nchw().cpu(), ref, 2 * tol, f"sub-pixel up2 {name}")
+    nine = ops.conv3x3(xp, ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=cout_tile), act=_lib.ACT_LRELU, up2=True,
+                       rows_per_wave=mb)
+    assert_close(sub.to_nchw().cpu(), nine.to_nchw().cpu(), 2 * tol, f"sub-pixel against nine taps {name}")
+    # f32 output: what is left against torch is the rounding of the tap sums and the f32 summation order
+    sub32 = ops.conv3x3(xp, ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=cout_tile, subpixel_up2=True),
+                        act=_lib.ACT_LRELU, up2=True, rows_per_wave=mb, out_dtype=_lib.F32)
+    assert_close(sub32.to_nchw().cpu(), ref, tol, f"sub-pixel up2 {name} (f32 out)")
+
+
+def test_upsampling_conv_subpixel_form_is_declined_where_it_does_not_apply():
+    x = ops.Planes.from_nchw(rnd("x", (1, 64, 8, 8), 1), _lib.F16)
+    pc = ops.PackedConv(rnd("w", (64, 64, 3, 3), 2, 0.1).numpy(), None, _lib.F16, subpixel_up2=True)
+    with pytest.raises(_lib.SrmiError, match="in_up2"):
+        ops.conv3x3(x, pc)                      # not an upsampling convolution
+    with pytest.raises(_lib.SrmiError, match="rows_per_wave"):
+        ops.conv3x3(x, pc, up2=True, rows_per_wave=4)
+    with pytest.raises(_lib.SrmiError):
+        ops.PackedConv(rnd("w", (64, 64, 3, 3), 2, 0.1).numpy(), None, _lib.F32, subpixel_up2=True)
+
+
 @pytest.mark.parametrize("dt,name,tol", DTYPES)
 @pytest.mark.parametrize("r", [2, 3])
 def test_pixel_shuffle_store(dt, name, tol, r):

@@ -6,7 +6,8 @@ activation, residual, dtype, image size and batch) against torch's fp32 conv2d o
 type, an int8 convolution for every fourth of them against the exact integer convolution, and as many bilinear u8
 resizes at random sizes against the oracle (bit-exact); the f16 convolutions with input counts in multiples of 32 also in
 their two Winograd forms against the CPU emulation of those (tools/winograd_emulation.py), every f16 / bf16 case also an RGB
-layer (3 outputs, 32..256 input channels, f32 and u8 results against the exact ones), and every third case a
+layer (3 outputs, 32..256 input channels, f32 and u8 results against the exact ones) and the convolution itself behind a
+nearest-x2 upsampling in its sub-pixel form, and every third case a
 channel-attention block in one kernel against its two-launch form (same bits).  Every network also runs a second f16
 engine with an f16 trunk (RCAN: one-kernel blocks; RRDBNet: a Winograd form of the dense-block convolutions).
 Prints one line per failing case and a summary; exit status 1 if anything failed.
@@ -95,6 +96,18 @@ def fuzz_ops(rng, cases):
             if g32.shape != core.shape or e3 > 5e-4 * max(float(core.abs().max()), 1e-6) or d8.max() > 1:
                 bad += 1
                 print(f"FAIL rgb layer dt={dt} cin={cin3} n={n} h={h} w={w}: {e3:.3g}, u8 max diff {d8.max()}", flush=True)
+        if dt != _lib.F32 and mb < 4:
+            # the same convolution behind a nearest-x2 upsampling, in its sub-pixel form (four 2x2 convolutions on the source grid)
+            hs, ws = (h + 1) // 2, (w + 1) // 2
+            xs = rq("xs", (n, cin, hs, ws))
+            refu = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), wt, b, padding=1)
+            refu = F.relu(refu) if act == _lib.ACT_RELU else F.leaky_relu(refu, 0.2) if act == _lib.ACT_LRELU else refu
+            pu = ops.PackedConv(wt.numpy(), b.numpy(), dt, cout_tile=cout_tile, subpixel_up2=True)
+            gu = ops.conv3x3(ops.Planes.from_nchw(xs, dt), pu, act=act, rows_per_wave=mb, up2=True).to_nchw().cpu()
+            eu, su = float((gu - refu).abs().max()), max(float(refu.abs().max()), 1e-6)
+            if gu.shape != refu.shape or eu > 2 * OP_TOL[dt] * su:
+                bad += 1
+                print(f"FAIL sub-pixel up2 dt={dt} cin={cin} cout={cout} tile={cout_tile} mb={mb} n={n} h={hs} w={ws}: {eu:.3g} on {su:.3g}", flush=True)
         if i % 3 == 0:
             # both convolutions of a channel-attention block in one kernel against the two-launch form: same bits
             xb, yb = rq("xb", (n, 64, h, w)), rq("yb", (n, 64, h, w))
