@@ -75,6 +75,33 @@ int main() {
             ++done;
         }
     }
+    // the sub-pixel form of an upsampling convolution (f16 / bf16 images [tile][stage][tap 2x2][row][32 bytes], bias per phase)
+    for (const Case& c : cases) {
+        if (c.cin % 16 || c.ps_r != 1 || c.cout % c.tile) continue;
+        for (int dt : {SRMI_F16, SRMI_BF16}) {
+            int nbias = 0;
+            const size_t bytes = srmi_pack_conv3x3_up2_bytes(dt, c.cout, c.cin, c.tile, &nbias);
+            if (!bytes || nbias != 4 * c.cout) { fprintf(stderr, "bad sub-pixel sizes for cout %d cin %d\n", c.cout, c.cin); return 1; }
+            std::vector<float> w((size_t)c.cout * c.cin * 9), b((size_t)c.cout, 0.25f);
+            uint32_t s = 2468013u + (uint32_t)done;
+            for (auto& v : w) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
+            std::vector<unsigned char> img(bytes, 0xCD), img2(bytes, 0x37);
+            std::vector<float> bias((size_t)nbias, -777.0f), bias2((size_t)nbias, -777.0f);
+            if (srmi_pack_conv3x3_up2(dt, c.cout, c.cin, c.tile, w.data(), b.data(), img.data(), bias.data()) ||
+                srmi_pack_conv3x3_up2(dt, c.cout, c.cin, c.tile, w.data(), nullptr, img2.data(), bias2.data())) {
+                fprintf(stderr, "sub-pixel pack failed: %s\n", srmi_last_error());
+                return 1;
+            }
+            if (memcmp(img.data(), img2.data(), bytes)) { fprintf(stderr, "sub-pixel image (cout %d, cin %d) has unwritten bytes\n", c.cout, c.cin); return 1; }
+            for (int i = 0; i < nbias; ++i)
+                if (bias[i] != 0.25f || bias2[i] != 0.f) { fprintf(stderr, "sub-pixel bias %d not written\n", i); return 1; }
+            ++done;
+        }
+    }
+    if (srmi_pack_conv3x3_up2_bytes(SRMI_F32, 64, 64, 32, nullptr) || srmi_pack_conv3x3_up2_bytes(SRMI_F16, 48, 64, 32, nullptr)) {
+        fprintf(stderr, "sub-pixel form accepted f32 or a ragged output count\n");
+        return 1;
+    }
     // rejected shapes return -1 with a message and write nothing
     unsigned char dummy[64];
     float fb[64];

@@ -237,6 +237,47 @@ def test_winograd_weight_packing_layout():
     assert L.srmi_pack_wino3x3(32, 24, w.ctypes.data, None, wp.ctypes.data, bp.ctypes.data) == -1
 
 
+def test_subpixel_upsampling_weight_packing():
+    """srmi_pack_conv3x3_up2 (no GPU): the packed image, read back as four 2x2 kernels per output channel, evaluated on the
+    SOURCE grid with torch reproduces conv3x3(nearest-x2 upsampling(x)) (realesrgan_model.py:115-116) up to the one
+    rounding of the summed taps; image layout [cout tile][16-channel stage][tap 2x2][row][chunk swizzle][8 halves] with packed
+    channel phase * cout + o, bias repeated per phase."""
+    import torch.nn.functional as F
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for cout, cin, tile in ((64, 32, 32), (64, 64, 64), (32, 48, 32)):
+        w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        nb = C.c_int(0)
+        nbytes = L.srmi_pack_conv3x3_up2_bytes(_lib.F16, cout, cin, tile, C.byref(nb))
+        ntile, nstage = 4 * cout // tile, cin // 16
+        assert nbytes == ntile * nstage * 4 * tile * 32 and nb.value == 4 * cout
+        wp = np.full(nbytes // 2, 0x7e00, np.uint16)
+        bp = np.full(nb.value, np.nan, np.float32)
+        assert L.srmi_pack_conv3x3_up2(_lib.F16, cout, cin, tile, w.ctypes.data, b.ctypes.data, wp.ctypes.data, bp.ctypes.data) == 0
+        assert np.array_equal(bp, np.tile(b, 4))
+        img = wp.view(np.float16).reshape(ntile, nstage, 4, tile, 2, 8).astype(np.float32)
+        # undo the 16-byte chunk swizzle: chunk c of image row r sits at c ^ ((r >> 3) & 1)
+        sw = (np.arange(tile) >> 3) & 1
+        for r in range(tile):
+            if sw[r]:
+                img[:, :, :, r] = img[:, :, :, r, ::-1].copy()
+        # weff[phase][o][ci][a][b]
+        weff = img.transpose(0, 3, 1, 4, 5, 2).reshape(4 * cout, cin, 2, 2).reshape(4, cout, cin, 2, 2)
+        x = torch.from_numpy(rng.standard_normal((1, cin, 7, 9)).astype(np.float32))
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), torch.from_numpy(w), torch.from_numpy(b), padding=1)
+        got = torch.empty_like(ref)
+        xp = F.pad(x, (1, 1, 1, 1))
+        for py in range(2):
+            for px in range(2):
+                # source rows y - 1 + py .. y + py, columns x - 1 + px .. x + px
+                win = xp[:, :, py:py + 8, px:px + 10]
+                got[:, :, py::2, px::2] = F.conv2d(win, torch.from_numpy(np.ascontiguousarray(weff[2 * py + px])), torch.from_numpy(b))
+        assert float((got - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max())
+    assert L.srmi_pack_conv3x3_up2_bytes(_lib.F32, 64, 64, 32, None) == 0
+    assert L.srmi_pack_conv3x3_up2_bytes(_lib.F16, 48, 64, 32, None) == 0
+
+
 def test_forward_without_gpu_fails_loudly():
     m = realesrgan_model.RRDBNet(num_block=1)
     with pytest.raises(_lib.SrmiError, match="no HIP device"):
